@@ -1,0 +1,165 @@
+/*
+ * vd_hip.h - C ABI of libvd_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind the
+ * Versatile-Diffusion sampling hot path.
+ *
+ * The reference (SHI-Labs/Versatile-Diffusion) has no native layer: every FLOP of the path is a
+ * stock torch op issued from Python.  This header is therefore the boundary the *new* Python
+ * modules (versatile-diffusion_amd/lib/model_zoo/...) bind with ctypes; each entry point names
+ * the reference code whose arithmetic it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - all pointers are device pointers owned by the caller (torch caching allocator); nothing is
+ *     allocated, freed or synchronised inside the library; every launch goes to `stream`
+ *   - activations are fp16, channels-last: [B, H, W, C] == (B*H*W, C) row-major
+ *   - weights are fp16, K-contiguous: Linear [out][in] as torch stores it, conv repacked once at
+ *     load time to [Cout][kh][kw][Cin]
+ *   - statistics (GroupNorm, LayerNorm, softmax) and MFMA accumulation are fp32
+ *   - return value: 0 on success, negative VD_ERR_* otherwise; vd_last_error() returns the
+ *     thread-local message of the last failure
+ */
+#ifndef VD_HIP_H
+#define VD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define VD_HIP_ABI_VERSION 1
+
+/* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
+#define VD_EPI_BIAS 1         /* + bias[n]                                                    */
+#define VD_EPI_ROWVEC 2       /* + rowvec[m / rows_per_batch][n]  (ResBlock "h + emb_out")    */
+#define VD_EPI_RESIDUAL 4     /* + res[m][n] after activation and alpha                       */
+#define VD_EPI_BIAS_ALONG_M 8 /* bias indexed by output row (V^T = Wv x^T in the VAE AttnBlock) */
+#define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
+
+#define VD_ACT_NONE 0
+#define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 128 rows as [64 val | 64 gate] */
+#define VD_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x)  (HF CLIP)                                 */
+#define VD_ACT_SILU 3
+
+/*
+ * One fused GEMM / implicit-GEMM convolution:
+ *    out[m][n] = ( act( sum_k A[m][k] W[n][k] + bias + rowvec ) ) * alpha + res[m][n]
+ * A[m][k] is gathered on the fly: m -> (b, oy, ox) over Hout x Wout, k -> (ky, kx, c) with c running
+ * over the channels of a0 (c0) then a1 (c1) -- i.e. torch.cat([a0, a1], dim=1) is never materialised --
+ * at input pixel ((oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups) (ups=1: nearest 2x upsample
+ * fused in front of the conv).  Plain matrices: set Hout = Wout = 0.
+ */
+typedef struct VdGemmDesc {
+    const void* a0;      /* fp16 activation source 0, row stride lda0 (elements)                 */
+    const void* a1;      /* optional fp16 source 1 (channel concat), row stride lda1             */
+    const void* w;       /* fp16 [N][ldw]                                                        */
+    const void* bias;    /* fp16 [N] (or [M] with VD_EPI_BIAS_ALONG_M)                            */
+    const void* rowvec;  /* fp16 [M / rows_per_batch][N]                                          */
+    const void* res;     /* fp16 [M][ldr]                                                        */
+    void* out;           /* fp16 (or fp32) [M][ldc]                                              */
+    float* ws;           /* split-K workspace (vd_gemm_workspace_bytes), may be NULL             */
+    int32_t M, N, K;
+    int32_t c0, c1, lda0, lda1, ldw, ldc, ldr;
+    int32_t Hin, Win, Hout, Wout, ksize, stride, pad, ups;
+    int32_t rows_per_batch;
+    int32_t flags, act;
+    float alpha;
+    int32_t batch;       /* blockIdx.z batches with the element strides below                    */
+    int32_t split_k;     /* 0 = heuristic                                                        */
+    int64_t stride_a, stride_w, stride_out, stride_res;
+} VdGemmDesc;
+
+/* Replaces nn.Conv2d / nn.Linear / torch.bmm call sites:
+ *   lib/model_zoo/openaimodel.py:89-117 (Upsample), :133-159 (Downsample), :254-274 (ResBlock._forward)
+ *   lib/model_zoo/attention.py:37-64 (GEGLU FF), :170-193 (q/k/v/out projections), :255-266 (proj_in/out)
+ *   lib/model_zoo/autokl_modules.py:42-79,82-141,150-202 (VAE convs, AttnBlock bmm)
+ *   HF CLIP linear layers reached from lib/model_zoo/clip.py:58-61,95-100 */
+int vd_gemm_f16(const VdGemmDesc* desc, hipStream_t stream);
+size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
+
+/* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
+ * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().
+ * Replaces GroupNorm32 + SiLU (lib/model_zoo/diffusion_utils.py:175-191, openaimodel.py:196-200,230-237),
+ * Normalize (attention.py:76-77, autokl_modules.py:38-39) and the torch.cat in vd.py:371. */
+int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int c1, const void* gamma, const void* beta,
+                          void* y, float* stats, int B, int HW, int groups, float eps, int apply_silu,
+                          hipStream_t stream);
+size_t vd_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+
+/* LayerNorm over the last dim of [rows][C]. Replaces nn.LayerNorm in BasicTransformerBlock
+ * (lib/model_zoo/attention.py:205-207) and the HF CLIP layer norms. */
+int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                     hipStream_t stream);
+
+/* Fused softmax(Q K^T * scale) V, online softmax, no score tensor in HBM.
+ * q [B][Nq][ldq], k/v [B][Nk][ldk/ldv], out [B][Nq][ldo]; head h occupies columns h*D..h*D+D-1.
+ * D in {40, 64, 80, 160}.  causal != 0 masks key > query (CLIP text tower).
+ * Replaces CrossAttention.forward einsum/softmax/einsum (lib/model_zoo/attention.py:176-191). */
+int vd_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                     int ldq, int ldk, int ldv, int ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so,
+                     float scale, int causal, hipStream_t stream);
+
+/* Row softmax fp32 [rows][n] -> fp16 (VAE AttnBlock, lib/model_zoo/autokl_modules.py:192). */
+int vd_softmax_rows_f32_f16(const float* s, void* p, int64_t rows, int n, hipStream_t stream);
+
+/* Sinusoidal timestep embedding, fp32 math, fp16 out [B][dim] = [cos | sin].
+ * Replaces timestep_embedding (lib/model_zoo/diffusion_utils.py:131-151). */
+int vd_timestep_embedding_f16(const int64_t* t, void* out, int B, int dim, float max_period, hipStream_t stream);
+
+/* Classifier-free-guidance combine + DDIM update in one pass (fp32 math):
+ *   e = e_u + s (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);
+ *   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise
+ * eps holds [e_uncond ; e_cond] (2n elements) when guided != 0, else n elements.
+ * Replaces p_sample_ddim (lib/model_zoo/ddim.py:144-170). */
+int vd_cfg_ddim_step_f16(const void* x, const void* eps, const void* noise, void* x_prev, void* pred_x0, int64_t n,
+                         int guided, float guidance_scale, float a_t, float a_prev, float sigma,
+                         float sqrt_one_minus_at, hipStream_t stream);
+
+/* q_sample: out = sa[b] * x0 + sb[b] * noise  (lib/model_zoo/vd.py:221-224). */
+int vd_q_sample_f16(const void* x0, const void* noise, const float* sa, const float* sb, void* out, int B,
+                    int64_t per_batch, hipStream_t stream);
+
+/* layout changes at the API boundary (reference tensors are NCHW) */
+int vd_nchw_to_nhwc_f16(const void* x, void* y, int B, int C, int H, int W, hipStream_t stream);
+int vd_nhwc_to_nchw_f16(const void* x, void* y, int B, int C, int H, int W, float scale, float shift, int clamp01,
+                        hipStream_t stream);
+
+/* Small-Cin im2col: A[m][kpad] (zero padded, k = (ky*ks+kx)*C + c) from a strided fp16 image, with the
+ * affine x*in_scale+in_shift applied to valid pixels (fuses `x*2-1`, autokl.py:34 and `z/scale`, vd.py:294). */
+int vd_im2col_small_f16(const void* x, void* a, int B, int C, int Hin, int Win, int Hout, int Wout, int ksize,
+                        int stride, int pad, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int kpad,
+                        float in_scale, float in_shift, hipStream_t stream);
+
+/* DiagonalGaussianDistribution.sample fused with the latent scale:
+ *   z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale ; moments channels-last [M][2*zc], z NCHW
+ * (lib/model_zoo/distributions.py:24-37, vd.py:282-289). */
+int vd_diag_gaussian_sample_f16(const void* moments, const void* noise, void* z, int B, int zc, int HW, float scale,
+                                hipStream_t stream);
+
+/* out = a * x + b * y (context mixing helpers, vd.py:383-396) */
+int vd_axpby_f16(const void* x, const void* y, void* out, float a, float b, int64_t n, hipStream_t stream);
+
+/* CLIP helpers (arithmetic of HF transformers CLIPModel as called from lib/model_zoo/clip.py) */
+int vd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int L, int C,
+                        hipStream_t stream);
+int vd_clip_vision_embed_f16(const void* patches, const void* class_emb, const void* pos_emb, const float* token_scale,
+                             void* out, int B, int L, int C, hipStream_t stream);
+int vd_patchify_f16(const void* pixels, void* a, int B, int C, int H, int W, int P, int kpad, hipStream_t stream);
+/* z[b][l][:] *= row_scale[b][l] / ||ref[b][:]||  (ref row = z[b][pool_idx[b]], or `ref` if given) */
+int vd_scale_by_row_norm_f16(void* z, const void* ref, const int32_t* pool_idx, const float* row_scale, int B, int L,
+                             int C, hipStream_t stream);
+
+/* diagnostics */
+const char* vd_last_error(void);
+int vd_abi_version(void);
+/* writes lane->(row,col) maps of the 32x32x16 f16 MFMA as observed on the device; used by tests */
+int vd_probe_mfma_layout(int32_t* out_a_k, int32_t* out_c_row, int32_t* out_c_col, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VD_HIP_H */

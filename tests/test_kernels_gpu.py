@@ -1,0 +1,376 @@
+"""Per-kernel numerics: every HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+All calls go through the C ABI (ctypes -> libvd_hip.so).  Tolerances are stated per test; inputs are
+fp16-rounded so the only differences are accumulation order / fp16 output rounding.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.float()
+    b = b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half().to(dev)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vd_hip import ops as o
+    return o
+
+
+def test_mfma_layout_probe(ops, dev):
+    """The kernels assume: C/D row=(r&3)+8*(r>>2)+4*(lane>>5), col=lane&31; A/B k-slots pair 1:1."""
+    a_k, c_row, c_col = ops.probe_mfma_layout(dev)
+    lanes = torch.arange(64).view(64, 1)
+    regs = torch.arange(16).view(1, 16)
+    exp_row = (regs & 3) + 8 * (regs >> 2) + 4 * (lanes >> 5)
+    exp_col = (lanes & 31).expand(64, 16)
+    assert torch.equal(c_row.long(), exp_row.long()), "C/D row map differs:\n%s" % c_row
+    assert torch.equal(c_col.long(), exp_col.long()), "C/D col map differs:\n%s" % c_col
+    assert a_k.tolist() == list(range(16)), "A/B k-slot pairing is not the identity: %s" % a_k.tolist()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 192, 128), (77, 768, 768), (4096, 64, 2560),
+                                   (33, 8, 64), (512, 1280, 1280), (130, 4, 320)])
+def test_gemm_plain(ops, dev, M, N, K):
+    a = rnd((M, K), dev, 1.0, 1)
+    w = rnd((N, K), dev, 0.05, 2)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w)
+    assert out.shape == (M, N)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_gemm_asymmetric_identity(ops, dev):
+    """A = I with an asymmetric W catches row/col swaps in the C write (guide rule: transpose-detecting)."""
+    K = 128
+    a = torch.eye(K, dtype=torch.float16, device=dev)
+    w = (torch.arange(192 * K, device=dev).reshape(192, K) % 97).half() / 16
+    out = ops.gemm(a, w)
+    assert torch.equal(out, w.t().contiguous())
+
+
+@pytest.mark.parametrize("act", ["none", "quick_gelu", "silu"])
+def test_gemm_epilogue(ops, dev, act):
+    M, N, K, rpb = 512, 320, 192, 128
+    a = rnd((M, K), dev, 1.0, 3)
+    w = rnd((N, K), dev, 0.05, 4)
+    bias = rnd((N,), dev, 0.5, 5)
+    rowvec = rnd((M // rpb, N), dev, 0.5, 6)
+    res = rnd((M, N), dev, 1.0, 7)
+    v = a.float() @ w.float().t() + bias.float() + rowvec.float().repeat_interleave(rpb, 0)
+    if act == "quick_gelu":
+        v = v * torch.sigmoid(1.702 * v)
+    elif act == "silu":
+        v = F.silu(v)
+    ref = v * 0.7 + res.float()
+    code = {"none": ops.ACT_NONE, "quick_gelu": ops.ACT_QUICK_GELU, "silu": ops.ACT_SILU}[act]
+    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_batch=rpb, res=res, act=code, alpha=0.7)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_gemm_geglu(ops, dev):
+    from vd_hip.pack import pack_geglu
+    M, C = 384, 320
+    x = rnd((M, C), dev, 1.0, 8)
+    w = rnd((8 * C, C), dev, 0.05, 9)
+    b = rnd((8 * C,), dev, 0.2, 10)
+    h = x.float() @ w.float().t() + b.float()
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wp, bp = pack_geglu(w, b)
+    out = ops.gemm(x, wp, bias=bp, act=ops.ACT_GEGLU)
+    assert out.shape == (M, 4 * C)
+    assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("split", [2, 5, 16])
+def test_gemm_split_k(ops, dev, split):
+    M, N, K = 192, 320, 64 * 40
+    a = rnd((M, K), dev, 1.0, 11)
+    w = rnd((N, K), dev, 0.03, 12)
+    bias = rnd((N,), dev, 0.5, 13)
+    res = rnd((M, N), dev, 1.0, 14)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    out = ops.gemm(a, w, bias=bias, res=res, split_k=split)
+    assert rel_l2(out, ref) < 2e-3
+    out2 = ops.gemm(a, w, bias=bias, res=res)  # heuristic split
+    assert rel_l2(out2, ref) < 2e-3
+
+
+def test_gemm_batched_f32_and_bias_along_m(ops, dev):
+    Bt, M, N, K = 3, 200, 136, 128
+    a = rnd((Bt, M, K), dev, 1.0, 15)
+    w = rnd((Bt, N, K), dev, 0.1, 16)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) * 0.25
+    out = ops.gemm(a, w, M=M, N=N, K=K, batch=Bt, strides=(M * K, N * K, M * N, 0), alpha=0.25, out_f32=True)
+    assert out.dtype == torch.float32 and out.shape == (Bt, M, N)
+    assert rel_l2(out, ref) < 1e-3
+    # shared A (stride 0), bias along M  (V^T = Wv x^T + bv)
+    wv = rnd((M, K), dev, 0.1, 17)
+    bv = rnd((M,), dev, 0.5, 18)
+    ref2 = torch.einsum("mk,bnk->bmn", wv.float(), w.float()) + bv.float().view(1, M, 1)
+    out2 = ops.gemm(wv, w, bias=bv, bias_along_m=True, M=M, N=N, K=K, batch=Bt, strides=(0, N * K, M * N, 0))
+    assert rel_l2(out2, ref2) < 2e-3
+
+
+def _conv_ref(x_nhwc, w, b, stride, pad, ups, pad_hi=None):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if pad_hi is not None:
+        x = F.pad(x, (pad, pad_hi, pad, pad_hi))
+        y = F.conv2d(x, w.float(), b.float() if b is not None else None, stride=stride)
+    else:
+        y = F.conv2d(x, w.float(), b.float() if b is not None else None, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=16, W=16, Cin=64, Cout=128, stride=1, pad=1, ups=0),
+    dict(B=2, H=16, W=16, Cin=320, Cout=320, stride=1, pad=1, ups=0),
+    dict(B=1, H=32, W=32, Cin=64, Cout=64, stride=2, pad=1, ups=0),
+    dict(B=2, H=8, W=8, Cin=128, Cout=64, stride=1, pad=1, ups=1),
+    dict(B=1, H=17, W=13, Cin=64, Cout=72, stride=1, pad=1, ups=0),
+    dict(B=1, H=16, W=16, Cin=64, Cout=64, stride=2, pad=0, ups=0, pad_hi=1),
+    dict(B=2, H=8, W=8, Cin=1280, Cout=1280, stride=1, pad=1, ups=0),
+    dict(B=1, H=64, W=64, Cin=128, Cout=3, stride=1, pad=1, ups=0),
+])
+def test_conv3x3(ops, dev, cfg):
+    from vd_hip.pack import pack_conv_weight
+    B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = rnd((B, H, W, Cin), dev, 1.0, 20)
+    w = rnd((Cout, Cin, 3, 3), dev, 0.03, 21)
+    b = rnd((Cout,), dev, 0.3, 22)
+    ref = _conv_ref(x, w, b, cfg["stride"], cfg["pad"], cfg["ups"], cfg.get("pad_hi"))
+    out = ops.conv2d_nhwc(x, pack_conv_weight(w), b, ksize=3, stride=cfg["stride"], pad=cfg["pad"], ups=cfg["ups"],
+                          pad_hi=cfg.get("pad_hi"))
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_conv3x3_concat_rowvec_residual(ops, dev):
+    """ResBlock first conv on cat([h, skip]) + emb broadcast; second conv + residual."""
+    from vd_hip.pack import pack_conv_weight
+    B, H, W, C0, C1, Cout = 2, 16, 16, 128, 64, 128
+    x0 = rnd((B, H, W, C0), dev, 1.0, 23)
+    x1 = rnd((B, H, W, C1), dev, 1.0, 24)
+    w = rnd((Cout, C0 + C1, 3, 3), dev, 0.03, 25)
+    b = rnd((Cout,), dev, 0.3, 26)
+    emb = rnd((B, Cout), dev, 0.5, 27)
+    res = rnd((B, H, W, Cout), dev, 1.0, 28)
+    ref = _conv_ref(torch.cat([x0, x1], -1), w, b, 1, 1, 0) + emb.float().view(B, 1, 1, Cout) + res.float()
+    out = ops.conv2d_nhwc(x0, pack_conv_weight(w), b, x1=x1, rowvec=emb, rows_per_batch=H * W, res=res)
+    assert rel_l2(out, ref) < 2e-3
+    # 1x1 skip conv on the concatenation
+    w1 = rnd((Cout, C0 + C1, 1, 1), dev, 0.05, 29)
+    ref1 = _conv_ref(torch.cat([x0, x1], -1), w1, b, 1, 0, 0)
+    out1 = ops.conv2d_nhwc(x0, pack_conv_weight(w1), b, x1=x1, ksize=1, pad=0)
+    assert rel_l2(out1, ref1) < 2e-3
+
+
+@pytest.mark.parametrize("B,HW,c0,c1,silu,eps", [(2, 4096, 320, 0, True, 1e-5), (2, 256, 1280, 1280, True, 1e-5),
+                                                 (3, 1024, 640, 320, True, 1e-5), (1, 64, 1280, 0, False, 1e-6),
+                                                 (1, 16384, 128, 0, True, 1e-6), (2, 4096, 320, 0, False, 1e-6),
+                                                 (1, 100, 256, 0, True, 1e-6), (1, 300, 1920, 0, True, 1e-5)])
+def test_groupnorm(ops, dev, B, HW, c0, c1, silu, eps):
+    x0 = rnd((B, HW, c0), dev, 2.0, 30) + 0.5
+    x1 = rnd((B, HW, c1), dev, 1.0, 31) if c1 else None
+    C = c0 + c1
+    gamma = rnd((C,), dev, 0.5, 32) + 1.0
+    beta = rnd((C,), dev, 0.5, 33)
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm_silu(x0, gamma, beta, x1=x1, groups=32, eps=eps, silu=silu)
+    assert out.shape == (B, HW, C)
+    assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 768), (513, 1280), (257, 1024), (5, 640)])
+def test_layernorm(ops, dev, rows, C):
+    x = rnd((rows, C), dev, 2.0, 40) + 0.3
+    g = rnd((C,), dev, 0.5, 41) + 1.0
+    b = rnd((C,), dev, 0.5, 42)
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5)
+    out = ops.layernorm(x, g, b, 1e-5)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def _attn_ref(q, k, v, heads, scale, causal):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    qf = q.float().view(B, Nq, heads, D).transpose(1, 2)
+    kf = k.float().view(B, Nk, heads, D).transpose(1, 2)
+    vf = v.float().view(B, Nk, heads, D).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if causal:
+        mask = torch.triu(torch.ones(Nq, Nk, dtype=torch.bool, device=q.device), 1)
+        s = s.masked_fill(mask, float("-inf"))
+    p = s.softmax(-1)
+    return (p @ vf).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,causal", [
+    (2, 8, 1024, 1024, 40, False), (1, 8, 4096, 4096, 40, False), (2, 8, 1024, 77, 40, False),
+    (2, 8, 256, 256, 80, False), (2, 8, 1024, 257, 80, False), (2, 8, 64, 64, 160, False),
+    (2, 8, 256, 77, 160, False), (3, 12, 77, 77, 64, True), (2, 16, 257, 257, 64, False),
+    (1, 8, 200, 514, 40, False), (1, 3, 130, 70, 64, True)])
+def test_attention(ops, dev, B, H, Nq, Nk, D, causal):
+    C = H * D
+    q = rnd((B, Nq, C), dev, 1.0, 50)
+    k = rnd((B, Nk, C), dev, 1.0, 51)
+    v = rnd((B, Nk, C), dev, 1.0, 52)
+    scale = D ** -0.5
+    ref = _attn_ref(q, k, v, H, scale, causal)
+    out = ops.attention(q, k, v, H, scale=scale, causal=causal)
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_attention_fused_qkv_views_and_spike(ops, dev):
+    """Strided column views of one fused projection; a spiked key forces a late running-max jump."""
+    B, N, H, D = 2, 512, 8, 40
+    C = H * D
+    qkv = rnd((B, N, 3 * C), dev, 1.0, 53)
+    qkv[:, 300, C:2 * C] *= 12.0  # one key with huge norm -> max jumps in tile 4
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), H, D ** -0.5, False)
+    out = ops.attention(q, k, v, H)
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_softmax_rows(ops, dev):
+    s = torch.randn(300, 4096, device=dev) * 5
+    ref = s.softmax(-1)
+    out = ops.softmax_rows(s)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_timestep_embedding(ops, dev):
+    t = torch.tensor([981, 1, 500, 21], dtype=torch.int64, device=dev)
+    dim = 320
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / half)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    out = ops.timestep_embedding(t, dim)
+    assert (out.float() - ref).abs().max().item() < 2e-3
+    # golden values from the reference
+    assert abs(out[0, 0].item() - 0.67995721) < 1e-3 and abs(out[0, half].item() - 0.73325181) < 1e-3
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_cfg_ddim_step(ops, dev, guided):
+    x = rnd((4, 4, 64, 64), dev, 1.0, 60)
+    eps = rnd((8 if guided else 4, 4, 64, 64), dev, 1.0, 61)
+    noise = rnd((4, 4, 64, 64), dev, 1.0, 62)
+    a_t, a_prev, sigma, s = 0.5888, 0.7521, 0.1, 7.5
+    e = eps.float()
+    if guided:
+        eu, ec = e.chunk(2)
+        e = eu + s * (ec - eu)
+    p0 = (x.float() - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    ref = math.sqrt(a_prev) * p0 + math.sqrt(1 - a_prev - sigma ** 2) * e + sigma * noise.float()
+    xp, px0 = ops.cfg_ddim_step(x, eps, guided=guided, guidance_scale=s, a_t=a_t, a_prev=a_prev, sigma=sigma,
+                                sqrt_one_minus_at=math.sqrt(1 - a_t), noise=noise)
+    assert rel_l2(xp, ref) < 1e-3 and rel_l2(px0, p0) < 1e-3
+
+
+def test_q_sample_axpby_layouts(ops, dev):
+    x0 = rnd((3, 4, 32, 32), dev, 1.0, 63)
+    nz = rnd((3, 4, 32, 32), dev, 1.0, 64)
+    sa = torch.tensor([0.9, 0.5, 0.1], device=dev)
+    sb = torch.tensor([0.3, 0.8, 0.99], device=dev)
+    ref = sa.view(3, 1, 1, 1) * x0.float() + sb.view(3, 1, 1, 1) * nz.float()
+    assert rel_l2(ops.q_sample(x0, nz, sa, sb), ref) < 1e-3
+    assert rel_l2(ops.axpby(x0, nz, 0.4, 0.6), 0.4 * x0.float() + 0.6 * nz.float()) < 1e-3
+    y = rnd((1, 7), dev, 1.0, 65)
+    assert rel_l2(ops.axpby(y, y, 2.0, 1.0), 3.0 * y.float()) < 1e-3
+    x = rnd((2, 5, 20, 33), dev, 1.0, 66)
+    nhwc = ops.nchw_to_nhwc(x)
+    assert torch.equal(nhwc, x.permute(0, 2, 3, 1).contiguous())
+    back = ops.nhwc_to_nchw(nhwc)
+    assert torch.equal(back, x)
+    img = ops.nhwc_to_nchw(nhwc, scale=0.5, shift=0.5, clamp01=True)
+    assert rel_l2(img, torch.clamp((x.float() + 1) / 2, 0, 1)) < 1e-3
+
+
+@pytest.mark.parametrize("layout,C,ks,stride,pad,pad_hi", [("nchw", 4, 3, 1, 1, None), ("nchw", 3, 3, 1, 1, None),
+                                                           ("nhwc", 8, 1, 1, 0, None), ("nhwc", 4, 1, 1, 0, None)])
+def test_im2col_small_conv(ops, dev, layout, C, ks, stride, pad, pad_hi):
+    from vd_hip.pack import pack_conv_weight_small
+    B, H, W, Cout = 2, 24, 20, 64
+    x = rnd((B, C, H, W), dev, 1.0, 70)
+    w = rnd((Cout, C, ks, ks), dev, 0.2, 71)
+    b = rnd((Cout,), dev, 0.3, 72)
+    ref = F.conv2d(x.float() * 2 - 1, w.float(), b.float(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    xin = x if layout == "nchw" else x.permute(0, 2, 3, 1).contiguous()
+    a, (Bo, Ho, Wo) = ops.im2col_small(xin, layout=layout, ksize=ks, stride=stride, pad=pad, in_scale=2.0, in_shift=-1.0)
+    out = ops.gemm(a, pack_conv_weight_small(w), bias=b).view(Bo, Ho, Wo, Cout)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_diag_gaussian_sample(ops, dev):
+    B, zc, H, W = 2, 4, 16, 16
+    mom = rnd((B, H, W, 2 * zc), dev, 2.0, 73)
+    nz = rnd((B, zc, H, W), dev, 1.0, 74)
+    m = mom.float().permute(0, 3, 1, 2)
+    mean, logvar = m.chunk(2, 1)
+    ref = (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * nz.float()) * 0.18215
+    out = ops.diag_gaussian_sample(mom, nz, B, zc, H, W, 0.18215)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_clip_helpers(ops, dev):
+    B, L, C, V = 2, 77, 768, 1000
+    ids = torch.randint(0, V, (B, L), device=dev)
+    tok = rnd((V, C), dev, 1.0, 80)
+    pos = rnd((L, C), dev, 1.0, 81)
+    assert rel_l2(ops.embed_tokens(ids, tok, pos), tok.float()[ids] + pos.float()) < 1e-3
+    # vision embed
+    P, G, Cv = 14, 4, 256
+    px = rnd((B, 3, G * P, G * P), dev, 1.0, 82)
+    wpe = rnd((Cv, 3, P, P), dev, 0.05, 83)
+    from vd_hip.pack import pack_patch_weight
+    a = ops.patchify(px, P)
+    pe = ops.gemm(a, pack_patch_weight(wpe)).view(B, G * G, Cv)
+    ref_pe = F.conv2d(px.float(), wpe.float(), stride=P).flatten(2).transpose(1, 2)
+    assert rel_l2(pe, ref_pe) < 2e-3
+    cls = rnd((Cv,), dev, 1.0, 84)
+    posv = rnd((G * G + 1, Cv), dev, 1.0, 85)
+    tsc = torch.rand(B, G * G + 1, device=dev)
+    ref_e = (torch.cat([cls.float().expand(B, 1, Cv), pe.float()], 1) + posv.float()) * tsc[..., None]
+    assert rel_l2(ops.clip_vision_embed(pe, cls, posv, tsc), ref_e) < 2e-3
+    # pooled-norm scaling
+    z = rnd((B, L, C), dev, 1.0, 86)
+    idx = torch.tensor([5, 76], dtype=torch.int32, device=dev)
+    ref_z = z.float() / z.float()[torch.arange(B), idx.long()].norm(dim=-1).view(B, 1, 1)
+    out = ops.scale_by_row_norm_(z.clone(), pool_idx=idx)
+    assert rel_l2(out, ref_z) < 2e-3
+    rs = torch.rand(B, L, device=dev)
+    out2 = ops.scale_by_row_norm_(z.clone(), row_scale=rs)
+    ref2 = z.float() / z.float()[:, 0:1].norm(dim=-1, keepdim=True) * rs[..., None]
+    assert rel_l2(out2, ref2) < 2e-3
+
+
+def test_error_reporting(ops, dev):
+    from vd_hip import VdHipError
+    a = rnd((64, 72), dev)
+    w = rnd((64, 72), dev)
+    with pytest.raises(VdHipError, match="multiple of 64"):
+        ops.gemm(a, w)
+    with pytest.raises(VdHipError, match="GPU"):
+        ops.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(64).half(), torch.zeros(64).half())

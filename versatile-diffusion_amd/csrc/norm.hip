@@ -1,0 +1,260 @@
+// GroupNorm(+SiLU) and LayerNorm for channels-last fp16 activations (gfx950).
+// HBM-bound: every element is read with 16-byte loads, statistics in fp32.
+//
+// GroupNorm runs as three launches: per-slab partial sums -> finalize (mean, rstd per (b, group))
+// -> normalise * gamma + beta (+SiLU).  The input may be the channel-concatenation of two tensors
+// (skip connections of the UNet up path), which is read in place.
+// Reference: GroupNorm32/normalization (lib/model_zoo/diffusion_utils.py:175-191), SiLU in
+// ResBlock.in_layers/out_layers (openaimodel.py:196-200,230-237), Normalize eps=1e-6
+// (attention.py:76-77, autokl_modules.py:38-39), nn.LayerNorm (attention.py:205-207).
+#include "vd_common.h"
+#include "../../include/vd_hip.h"
+
+namespace {
+
+constexpr int GN_MAX_POS = 2;  // channel-chunk positions per thread: supports C <= 2*256*8 = 4096
+
+struct GnGeom {
+    int C, C8, TC, R, npos, rows_per_chunk, nchunk;
+};
+
+inline GnGeom gn_geom(int HW, int C) {
+    GnGeom g;
+    g.C = C;
+    g.C8 = C / 8;
+    g.TC = g.C8 < 256 ? g.C8 : 256;
+    g.R = 256 / g.TC;
+    g.npos = (g.C8 + g.TC - 1) / g.TC;
+    int rpc = 16384 / C;
+    if (rpc < 1) rpc = 1;
+    const int min_rpc = (HW + 255) / 256;
+    if (rpc < min_rpc) rpc = min_rpc;
+    rpc = ((rpc + g.R - 1) / g.R) * g.R;
+    g.rows_per_chunk = rpc;
+    g.nchunk = (HW + rpc - 1) / rpc;
+    return g;
+}
+
+__device__ __forceinline__ const f16* gn_src(const f16* x0, int c0, const f16* x1, int c1, size_t row, int ch) {
+    return (ch < c0) ? (x0 + row * c0 + ch) : (x1 + row * c1 + (ch - c0));
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, const f16* x1, int c1, float* part,
+                                                         int HW, int groups, GnGeom g) {
+    __shared__ float ls[64 * 2];
+    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    if (tid < groups * 2) ls[tid] = 0.f;
+    __syncthreads();
+    const int cg = g.C / groups;
+    const int tc = tid % g.TC, rl = tid / g.TC;
+    if (rl < g.R) {
+        const int r0 = chunk * g.rows_per_chunk;
+        int r1 = r0 + g.rows_per_chunk;
+        if (r1 > HW) r1 = HW;
+        for (int pos = 0; pos < g.npos; ++pos) {
+            const int cc = tc + pos * g.TC;
+            if (cc >= g.C8) break;
+            float s[8], q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+            for (int r = r0 + rl; r < r1; r += g.R) {
+                U4H8 t;
+                t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + r, cc * 8));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = (float)t.e[i];
+                    s[i] += v;
+                    q[i] += v * v;
+                }
+            }
+            // fold the (up to 8) channels into their groups, one LDS atomic per run
+            int gcur = (cc * 8) / cg;
+            float as = 0.f, aq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gi = (cc * 8 + i) / cg;
+                if (gi != gcur) {
+                    atomicAdd(&ls[gcur * 2], as);
+                    atomicAdd(&ls[gcur * 2 + 1], aq);
+                    as = aq = 0.f;
+                    gcur = gi;
+                }
+                as += s[i];
+                aq += q[i];
+            }
+            atomicAdd(&ls[gcur * 2], as);
+            atomicAdd(&ls[gcur * 2 + 1], aq);
+        }
+    }
+    __syncthreads();
+    if (tid < groups * 2) part[((size_t)b * g.nchunk + chunk) * groups * 2 + tid] = ls[tid];
+}
+
+// one block per batch element: mean / rstd per group
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, float* stat, int nchunk, int groups,
+                                                          float inv_count, float eps) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float ls[256];
+    // thread t accumulates entry (t % (2*groups)) over chunks t/(2*groups), stride 256/(2*groups)
+    const int ne = groups * 2;
+    const int e = tid % ne, lanes = 256 / ne, cl = tid / ne;
+    float acc = 0.f;
+    if (cl < lanes)
+        for (int c = cl; c < nchunk; c += lanes) acc += part[((size_t)b * nchunk + c) * ne + e];
+    ls[tid] = (cl < lanes) ? acc : 0.f;
+    __syncthreads();
+    if (tid < ne) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += ls[l * ne + tid];
+        ls[tid] = t;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const float mean = ls[tid * 2] * inv_count;
+        float var = ls[tid * 2 + 1] * inv_count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        stat[((size_t)b * groups + tid) * 2] = mean;
+        stat[((size_t)b * groups + tid) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
+                                                       const f16* beta, const float* stat, f16* y, int HW, int groups,
+                                                       int apply_silu, GnGeom g) {
+    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int cg = g.C / groups;
+    const int tc = tid % g.TC, rl = tid / g.TC;
+    if (rl >= g.R) return;
+    const int r0 = chunk * g.rows_per_chunk;
+    int r1 = r0 + g.rows_per_chunk;
+    if (r1 > HW) r1 = HW;
+    float sc[GN_MAX_POS][8], sh[GN_MAX_POS][8];
+#pragma unroll
+    for (int pos = 0; pos < GN_MAX_POS; ++pos) {
+        const int cc = tc + pos * g.TC;
+        if (pos < g.npos && cc < g.C8) {
+            U4H8 ga, be;
+            ga.u = *reinterpret_cast<const uint4*>(gamma + cc * 8);
+            be.u = *reinterpret_cast<const uint4*>(beta + cc * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gi = (cc * 8 + i) / cg;
+                const float mean = stat[((size_t)b * groups + gi) * 2];
+                const float rstd = stat[((size_t)b * groups + gi) * 2 + 1];
+                sc[pos][i] = rstd * (float)ga.e[i];
+                sh[pos][i] = (float)be.e[i] - mean * sc[pos][i];
+            }
+        }
+    }
+#pragma unroll
+    for (int pos = 0; pos < GN_MAX_POS; ++pos) {
+        const int cc = tc + pos * g.TC;
+        if (pos < g.npos && cc < g.C8) {
+            for (int r = r0 + rl; r < r1; r += g.R) {
+                const size_t row = (size_t)b * HW + r;
+                U4H8 t, o;
+                t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, row, cc * 8));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = (float)t.e[i] * sc[pos][i] + sh[pos][i];
+                    if (apply_silu) v = vd_silu(v);
+                    o.e[i] = (f16)v;
+                }
+                *reinterpret_cast<uint4*>(y + row * g.C + cc * 8) = o.u;
+            }
+        }
+    }
+}
+
+// LayerNorm: one wave per row, row kept in registers (two-pass variance), C <= 2048, C % 8 == 0
+constexpr int LN_MAX_CH = 4;
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* gamma, const f16* beta, f16* y,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    const f16* xr = x + (size_t)row * C;
+    float v[LN_MAX_CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CH; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(xr + cc * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[j][i] = (float)t.e[i];
+                s += v[j][i];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CH; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dlt = v[j][i] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    f16* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CH; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+            U4H8 ga, be, o;
+            ga.u = *reinterpret_cast<const uint4*>(gamma + cc * 8);
+            be.u = *reinterpret_cast<const uint4*>(beta + cc * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = (f16)((v[j][i] - mean) * rstd * (float)ga.e[i] + (float)be.e[i]);
+            *reinterpret_cast<uint4*>(yr + cc * 8) = o.u;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vd_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+    const GnGeom g = gn_geom(HW, C);
+    return ((size_t)B * g.nchunk * groups * 2 + (size_t)B * groups * 2) * sizeof(float);
+}
+
+extern "C" int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int c1, const void* gamma,
+                                     const void* beta, void* y, float* stats, int B, int HW, int groups, float eps,
+                                     int apply_silu, hipStream_t stream) {
+    if (x1 == nullptr) c1 = 0;
+    const int C = c0 + c1;
+    VD_REQUIRE(x0 && gamma && beta && y && stats, "vd_groupnorm_silu_f16: null pointer");
+    VD_REQUIRE(B > 0 && HW > 0 && C > 0, "vd_groupnorm_silu_f16: empty input");
+    VD_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "vd_groupnorm_silu_f16: bad groups=%d for C=%d", groups, C);
+    VD_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0, "vd_groupnorm_silu_f16: channel counts must be multiples of 8 (c0=%d c1=%d)", c0, c1);
+    VD_REQUIRE(C <= GN_MAX_POS * 256 * 8, "vd_groupnorm_silu_f16: C=%d too large", C);
+    const GnGeom g = gn_geom(HW, C);
+    float* part = stats;
+    float* stat = stats + (size_t)B * g.nchunk * groups * 2;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1,
+                       c1, part, HW, groups, g);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part, stat, g.nchunk, groups,
+                       1.0f / ((float)HW * (float)(C / groups)), eps);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1, c1,
+                       (const f16*)gamma, (const f16*)beta, stat, (f16*)y, HW, groups, apply_silu, g);
+    return vd_check_launch("vd_groupnorm_silu_f16");
+}
+
+extern "C" int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,
+                                float eps, hipStream_t stream) {
+    VD_REQUIRE(x && gamma && beta && y, "vd_layernorm_f16: null pointer");
+    VD_REQUIRE(rows > 0 && C > 0, "vd_layernorm_f16: empty input");
+    VD_REQUIRE(C % 8 == 0 && C <= LN_MAX_CH * 64 * 8, "vd_layernorm_f16: C=%d unsupported (need C%%8==0, C<=2048)", C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const f16*)x, (const f16*)gamma,
+                       (const f16*)beta, (f16*)y, rows, C, eps);
+    return vd_check_launch("vd_layernorm_f16");
+}

@@ -1,0 +1,56 @@
+// Shared device/host helpers for the vd_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VD_OK 0
+#define VD_ERR_ARG (-1)
+#define VD_ERR_LAUNCH (-2)
+#define VD_ERR_UNSUPPORTED (-3)
+
+// Thread-local last-error text, see vd_last_error() in capi.hip
+void vd_set_error(const char* fmt, ...);
+int vd_check_launch(const char* what);
+
+#define VD_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            vd_set_error(__VA_ARGS__);        \
+            return VD_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+union U4H8 {
+    uint4 u;
+    f16x8 h;
+    f16 e[8];
+};
+union U2H4 {
+    uint2 u;
+    f16x4 h;
+    f16 e[4];
+};
+
+__device__ __forceinline__ float vd_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact erf GELU (reference: F.gelu default, lib/model_zoo/attention.py:44)
+__device__ __forceinline__ float vd_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// quick GELU used by the HF CLIP towers (x * sigmoid(1.702 x))
+__device__ __forceinline__ float vd_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

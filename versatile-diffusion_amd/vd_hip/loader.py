@@ -1,0 +1,84 @@
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+_LIB_PATH = os.path.join(_PKG, "libvd_hip.so")
+_lib = None
+
+
+class VdHipError(RuntimeError):
+    pass
+
+
+class VdGemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("a0", ctypes.c_void_p), ("a1", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("rowvec", ctypes.c_void_p), ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ws", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("c0", ctypes.c_int32), ("c1", ctypes.c_int32), ("lda0", ctypes.c_int32), ("lda1", ctypes.c_int32),
+        ("ldw", ctypes.c_int32), ("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
+        ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32), ("Hout", ctypes.c_int32), ("Wout", ctypes.c_int32),
+        ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("ups", ctypes.c_int32),
+        ("rows_per_batch", ctypes.c_int32), ("flags", ctypes.c_int32), ("act", ctypes.c_int32),
+        ("alpha", ctypes.c_float), ("batch", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("stride_a", ctypes.c_int64), ("stride_w", ctypes.c_int64), ("stride_out", ctypes.c_int64),
+        ("stride_res", ctypes.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/vd_hip.h one to one (checked by tests/test_capi_symbols.py)
+_P, _I, _F, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
+PROTOTYPES = {
+    "vd_gemm_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P]),
+    "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
+    "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "vd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "vd_attention_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P]),
+    "vd_softmax_rows_f32_f16": (_I, [_P, _P, _L, _I, _P]),
+    "vd_timestep_embedding_f16": (_I, [_P, _P, _I, _I, _F, _P]),
+    "vd_cfg_ddim_step_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    "vd_q_sample_f16": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
+    "vd_nchw_to_nhwc_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "vd_nhwc_to_nchw_f16": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "vd_im2col_small_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _F, _F, _P]),
+    "vd_diag_gaussian_sample_f16": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "vd_axpby_f16": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "vd_embed_tokens_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vd_clip_vision_embed_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vd_patchify_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vd_scale_by_row_norm_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vd_last_error": (ctypes.c_char_p, []),
+    "vd_abi_version": (_I, []),
+    "vd_probe_mfma_layout": (_I, [_P, _P, _P, _P]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def available():
+    return os.path.exists(_LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises VdHipError when the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise VdHipError(
+            "libvd_hip.so not found at %s -- build it with `python versatile-diffusion_amd/build.py` "
+            "(there is no CPU fallback for the product path)" % _LIB_PATH)
+    try:
+        h = ctypes.CDLL(_LIB_PATH)
+    except OSError as e:  # e.g. no ROCm runtime on this host
+        raise VdHipError("cannot load %s: %s" % (_LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return h

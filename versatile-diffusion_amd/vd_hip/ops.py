@@ -1,0 +1,313 @@
+"""Tensor-level wrappers over the C ABI (include/vd_hip.h).
+
+Inputs are torch CUDA(HIP) fp16 tensors; outputs are allocated with torch (caching allocator) and every
+kernel is enqueued on torch's current stream, so `torch.cuda.graph` capture and stream semantics hold.
+No arithmetic is done in torch here.
+"""
+import ctypes
+import math
+
+import torch
+
+from .loader import VdGemmDesc, VdHipError, lib
+
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32 = 1, 2, 4, 8, 16
+ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(rc):
+    if rc != 0:
+        raise VdHipError("vd_hip call failed (%d): %s" % (rc, lib().vd_last_error().decode()))
+
+
+def _req(t, name, dtype=torch.float16):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise VdHipError("%s must live on the GPU (no CPU fallback in the product path)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise VdHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise VdHipError("%s must be contiguous" % name)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch per (device, stream, tag); consecutive kernels on one stream serialise on it."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
+         conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
+         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None):
+    """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
+
+    conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
+    """
+    _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
+    d = VdGemmDesc()
+    if K is None:
+        K = w.shape[-1]
+    if N is None:
+        N = w.shape[-2]
+    if M is None:
+        M = a0.numel() // a0.shape[-1] // max(batch, 1) if conv is None else None
+    if conv is not None:
+        d.Hin, d.Win, d.Hout, d.Wout = conv["Hin"], conv["Win"], conv["Hout"], conv["Wout"]
+        d.ksize, d.stride, d.pad, d.ups = conv.get("ksize", 1), conv.get("stride", 1), conv.get("pad", 0), conv.get("ups", 0)
+        if M is None:
+            M = conv["B"] * d.Hout * d.Wout
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.c0 = int(c0) if c0 else int(a0.shape[-1])
+    d.c1 = int(c1) if c1 else (int(a1.shape[-1]) if a1 is not None else 0)
+    d.lda0, d.lda1, d.ldw, d.ldc, d.ldr = int(lda0), int(lda1), int(ldw), int(ldc), int(ldr)
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        shape = out_shape if out_shape is not None else ((batch, M, n_out) if batch > 1 else (M, n_out))
+        out = torch.empty(shape, dtype=torch.float32 if out_f32 else torch.float16, device=a0.device)
+    else:
+        _req(out, "out", torch.float32 if out_f32 else torch.float16)
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+    if bias_along_m:
+        flags |= EPI_BIAS_ALONG_M
+    if rowvec is not None:
+        flags |= EPI_ROWVEC
+        d.rows_per_batch = int(rows_per_batch)
+    if res is not None:
+        flags |= EPI_RESIDUAL
+    if out_f32:
+        flags |= EPI_OUT_F32
+    d.flags, d.act, d.alpha = flags, int(act), float(alpha)
+    d.batch, d.split_k = int(batch), int(split_k)
+    d.stride_a, d.stride_w, d.stride_out, d.stride_res = [int(s) for s in strides]
+    d.a0, d.a1, d.w = a0.data_ptr(), (a1.data_ptr() if a1 is not None else None), w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.rowvec = rowvec.data_ptr() if rowvec is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.out = out.data_ptr()
+    # split-K slabs only pay for small-M, deep-K problems; mirror the library heuristic's trigger cheaply
+    if act != ACT_GEGLU and (split_k > 1 or (M * N <= 192 * 64 * 64 and K >= 1024)):
+        nb = max(batch, 1) * 16 * M * N * 4
+        d.ws = workspace(nb, a0.device, "gemm").data_ptr()
+    else:
+        d.ws = None
+    _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
+    return out
+
+
+def linear(x, w, bias=None, **kw):
+    """x [..., K] @ w[N, K]^T (+bias) -> [..., N]"""
+    lead = x.shape[:-1]
+    act = kw.get("act", ACT_NONE)
+    n_out = w.shape[0] // 2 if act == ACT_GEGLU else w.shape[0]
+    out = gemm(x, w, bias=bias, M=x.numel() // x.shape[-1], **kw)
+    return out.view(*lead, n_out)
+
+
+def conv2d_nhwc(x, w_packed, bias=None, *, ksize=3, stride=1, pad=1, ups=0, x1=None, cout=None, pad_hi=None, **kw):
+    """x [B, H, W, C] (optionally ++ x1 on channels) -> [B, Hout, Wout, Cout]; w_packed [Cout][ks*ks*(C0+C1)]."""
+    B, H, W, _ = x.shape
+    Hv, Wv = H << ups, W << ups
+    ph = pad if pad_hi is None else pad_hi
+    Hout = (Hv + pad + ph - ksize) // stride + 1
+    Wout = (Wv + pad + ph - ksize) // stride + 1
+    cout = w_packed.shape[0] if cout is None else cout
+    conv = dict(B=B, Hin=H, Win=W, Hout=Hout, Wout=Wout, ksize=ksize, stride=stride, pad=pad, ups=ups)
+    out = gemm(x, w_packed, a1=x1, bias=bias, conv=conv, N=cout, K=w_packed.shape[1], out_shape=(B, Hout, Wout, cout), **kw)
+    return out
+
+
+def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, out=None):
+    """GroupNorm(+SiLU) over channels-last x [B, ..., C] (++ x1)."""
+    _req(x, "x"); _req(x1, "x1"); _req(gamma, "gamma"); _req(beta, "beta")
+    B = x.shape[0]
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x.numel() // (B * c0)
+    C = c0 + c1
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
+    nb = lib().vd_groupnorm_workspace_bytes(B, HW, C, groups)
+    ws = workspace(nb, x.device, "gn")
+    _check(lib().vd_groupnorm_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), B, HW,
+                                       groups, float(eps), 1 if silu else 0, _stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().vd_layernorm_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, C, float(eps), _stream()))
+    return out
+
+
+def attention(q, k, v, heads, *, scale=None, causal=False, out=None):
+    """q [B, Nq, *], k/v [B, Nk, *]: last-dim views (possibly column slices of a fused projection) with stride 1.
+
+    Head h uses columns h*D:(h+1)*D of each.  Returns [B, Nq, heads*D] contiguous."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(-1) != 1 or t.dim() != 3:
+            raise VdHipError("%s must be a 3-d fp16 GPU tensor with unit inner stride" % n)
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    if out is None:
+        out = torch.empty((B, Nq, C), dtype=torch.float16, device=q.device)
+    if scale is None:
+        scale = D ** -0.5
+    _check(lib().vd_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, q.stride(1), k.stride(1),
+                                  v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                  float(scale), 1 if causal else 0, _stream()))
+    return out
+
+
+def softmax_rows(s, out=None):
+    _req(s, "s", torch.float32)
+    n = s.shape[-1]
+    rows = s.numel() // n
+    if out is None:
+        out = torch.empty(s.shape, dtype=torch.float16, device=s.device)
+    _check(lib().vd_softmax_rows_f32_f16(_ptr(s), _ptr(out), rows, n, _stream()))
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    _req(t, "t", torch.int64)
+    out = torch.empty((t.shape[0], dim), dtype=torch.float16, device=t.device)
+    _check(lib().vd_timestep_embedding_f16(_ptr(t), _ptr(out), t.shape[0], dim, float(max_period), _stream()))
+    return out
+
+
+def cfg_ddim_step(x, eps, *, guided, guidance_scale, a_t, a_prev, sigma, sqrt_one_minus_at, noise=None,
+                  want_pred_x0=True):
+    _req(x, "x"); _req(eps, "eps"); _req(noise, "noise")
+    n = x.numel()
+    if eps.numel() != (2 * n if guided else n):
+        raise VdHipError("eps has %d elements, expected %d" % (eps.numel(), 2 * n if guided else n))
+    x_prev = torch.empty_like(x)
+    pred_x0 = torch.empty_like(x) if want_pred_x0 else None
+    _check(lib().vd_cfg_ddim_step_f16(_ptr(x), _ptr(eps), _ptr(noise), _ptr(x_prev), _ptr(pred_x0), n, 1 if guided else 0,
+                                      float(guidance_scale), float(a_t), float(a_prev), float(sigma),
+                                      float(sqrt_one_minus_at), _stream()))
+    return x_prev, pred_x0
+
+
+def q_sample(x0, noise, sa, sb):
+    _req(x0, "x0"); _req(noise, "noise"); _req(sa, "sa", torch.float32); _req(sb, "sb", torch.float32)
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    _check(lib().vd_q_sample_f16(_ptr(x0), _ptr(noise), _ptr(sa), _ptr(sb), _ptr(out), B, x0.numel() // B, _stream()))
+    return out
+
+
+def nchw_to_nhwc(x):
+    _req(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.float16, device=x.device)
+    _check(lib().vd_nchw_to_nhwc_f16(_ptr(x), _ptr(y), B, C, H, W, _stream()))
+    return y
+
+
+def nhwc_to_nchw(x, scale=1.0, shift=0.0, clamp01=False):
+    _req(x, "x")
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float16, device=x.device)
+    _check(lib().vd_nhwc_to_nchw_f16(_ptr(x), _ptr(y), B, C, H, W, float(scale), float(shift), 1 if clamp01 else 0, _stream()))
+    return y
+
+
+def im2col_small(x, *, layout, ksize, stride=1, pad=1, pad_hi=None, in_scale=1.0, in_shift=0.0):
+    """Small-Cin im2col. layout 'nchw' or 'nhwc'. Returns (A [M, kpad], (B, Hout, Wout))."""
+    _req(x, "x")
+    if layout == "nchw":
+        B, C, H, W = x.shape
+        sb, sc, sy, sx = C * H * W, H * W, W, 1
+    else:
+        B, H, W, C = x.shape
+        sb, sc, sy, sx = H * W * C, 1, W * C, C
+    ph = pad if pad_hi is None else pad_hi
+    Hout = (H + pad + ph - ksize) // stride + 1
+    Wout = (W + pad + ph - ksize) // stride + 1
+    kk = ksize * ksize * C
+    kpad = ((kk + 63) // 64) * 64
+    a = torch.empty((B * Hout * Wout, kpad), dtype=torch.float16, device=x.device)
+    _check(lib().vd_im2col_small_f16(_ptr(x), _ptr(a), B, C, H, W, Hout, Wout, ksize, stride, pad, sb, sc, sy, sx, kpad,
+                                     float(in_scale), float(in_shift), _stream()))
+    return a, (B, Hout, Wout)
+
+
+def diag_gaussian_sample(moments, noise, B, zc, H, W, scale):
+    _req(moments, "moments"); _req(noise, "noise")
+    z = torch.empty((B, zc, H, W), dtype=torch.float16, device=moments.device)
+    _check(lib().vd_diag_gaussian_sample_f16(_ptr(moments), _ptr(noise), _ptr(z), B, zc, H * W, float(scale), _stream()))
+    return z
+
+
+def axpby(x, y, a, b, out=None):
+    _req(x, "x"); _req(y, "y")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().vd_axpby_f16(_ptr(x), _ptr(y), _ptr(out), float(a), float(b), x.numel(), _stream()))
+    return out
+
+
+def embed_tokens(ids, tok_emb, pos_emb):
+    _req(ids, "ids", torch.int64); _req(tok_emb, "tok_emb"); _req(pos_emb, "pos_emb")
+    B, L = ids.shape
+    C = tok_emb.shape[1]
+    out = torch.empty((B, L, C), dtype=torch.float16, device=ids.device)
+    _check(lib().vd_embed_tokens_f16(_ptr(ids), _ptr(tok_emb), _ptr(pos_emb), _ptr(out), B, L, C, _stream()))
+    return out
+
+
+def clip_vision_embed(patches, class_emb, pos_emb, token_scale=None):
+    _req(patches, "patches"); _req(class_emb, "class_emb"); _req(pos_emb, "pos_emb"); _req(token_scale, "token_scale", torch.float32)
+    B, Lm1, C = patches.shape
+    out = torch.empty((B, Lm1 + 1, C), dtype=torch.float16, device=patches.device)
+    _check(lib().vd_clip_vision_embed_f16(_ptr(patches), _ptr(class_emb), _ptr(pos_emb), _ptr(token_scale), _ptr(out), B,
+                                          Lm1 + 1, C, _stream()))
+    return out
+
+
+def patchify(pixels, P):
+    _req(pixels, "pixels")
+    B, C, H, W = pixels.shape
+    kk = C * P * P
+    kpad = ((kk + 63) // 64) * 64
+    a = torch.empty((B * (H // P) * (W // P), kpad), dtype=torch.float16, device=pixels.device)
+    _check(lib().vd_patchify_f16(_ptr(pixels), _ptr(a), B, C, H, W, P, kpad, _stream()))
+    return a
+
+
+def scale_by_row_norm_(z, *, ref=None, pool_idx=None, row_scale=None):
+    _req(z, "z"); _req(ref, "ref"); _req(pool_idx, "pool_idx", torch.int32); _req(row_scale, "row_scale", torch.float32)
+    B, L, C = z.shape
+    _check(lib().vd_scale_by_row_norm_f16(_ptr(z), _ptr(ref), _ptr(pool_idx), _ptr(row_scale), B, L, C, _stream()))
+    return z
+
+
+def probe_mfma_layout(device):
+    a_k = torch.full((16,), -2, dtype=torch.int32, device=device)
+    c_row = torch.zeros((64, 16), dtype=torch.int32, device=device)
+    c_col = torch.zeros((64, 16), dtype=torch.int32, device=device)
+    _check(lib().vd_probe_mfma_layout(_ptr(a_k), _ptr(c_row), _ptr(c_col), _stream()))
+    return a_k.cpu(), c_row.cpu(), c_col.cpu()

@@ -1,0 +1,43 @@
+"""One-time weight re-layouts (views/permutes only, done at load time, never in the step loop)."""
+import torch
+
+
+def pack_conv_weight(w):
+    """torch conv weight [Cout, Cin, kh, kw] -> K-contiguous [Cout, kh*kw*Cin] with k = (ky, kx, cin)."""
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def pack_conv_weight_small(w, kpad=None):
+    """Same ordering, zero padded along K to a multiple of 64 (matches vd_im2col_small_f16)."""
+    p = pack_conv_weight(w)
+    k = p.shape[1]
+    kpad = ((k + 63) // 64) * 64 if kpad is None else kpad
+    out = torch.zeros((p.shape[0], kpad), dtype=p.dtype, device=p.device)
+    out[:, :k] = p
+    return out
+
+
+def pack_patch_weight(w, kpad=None):
+    """CLIP patch embedding conv [Cout, C, P, P] -> [Cout, kpad], k = (c, py, px) (matches vd_patchify_f16)."""
+    co = w.shape[0]
+    p = w.reshape(co, -1)
+    k = p.shape[1]
+    kpad = ((k + 63) // 64) * 64 if kpad is None else kpad
+    out = torch.zeros((co, kpad), dtype=p.dtype, device=p.device)
+    out[:, :k] = p
+    return out
+
+
+def pack_geglu(w, b=None):
+    """GEGLU proj weight [2*inner, K] (rows: values then gates) -> per 128-row group [64 value | 64 gate]."""
+    two_inner, k = w.shape
+    inner = two_inner // 2
+    assert inner % 64 == 0, "GEGLU inner dim must be a multiple of 64"
+    val = w[:inner].reshape(inner // 64, 64, k)
+    gate = w[inner:].reshape(inner // 64, 64, k)
+    wp = torch.cat([val, gate], dim=1).reshape(two_inner, k).contiguous()
+    bp = None
+    if b is not None:
+        bp = torch.cat([b[:inner].reshape(-1, 64), b[inner:].reshape(-1, 64)], dim=1).reshape(-1).contiguous()
+    return wp, bp
