@@ -1,0 +1,155 @@
+"""The oracle (oracle/vd_oracle.py) against fixtures produced by the reference itself (oracle/gen_golden.py).
+
+CPU only.  fp32 vs fp32, so tolerances are tight: 1e-5 relative L2 (different op order only); the DDIM index
+schedule and the schedule buffers must be bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, vd_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: v for k, v in np.load(os.path.join(GOLD, name), allow_pickle=False).items()}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(GOLD, "meta.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def tiny_sd(meta):
+    g = load("unet_tiny.npz")
+    shapes = {str(k): tuple(json.loads(str(s))) for k, s in zip(g["state_keys"], g["state_shapes"])}
+    sd = synth.synth_state_dict(shapes, meta["seed"])
+    sd.update(O.register_schedule())
+    return sd
+
+
+def test_schedule_bit_exact():
+    g = load("schedule.npz")
+    s = O.register_schedule()
+    for k, v in s.items():
+        assert np.array_equal(v.numpy(), g[k]), k
+    # known answers quoted in SURVEY.md 8c
+    assert s["betas"][0].item() == pytest.approx(0.00085, abs=1e-9)
+    assert s["alphas_cumprod"][999].item() == np.float32(0.004660098347812891)
+    for steps in (50, 10, 5, 4):
+        d = O.ddim_schedule(s["alphas_cumprod"], steps, 0.0)
+        assert np.array_equal(d["timesteps"], g["ddim%d_timesteps" % steps])
+        assert np.array_equal(d["alphas"].numpy(), g["ddim%d_alphas" % steps])
+        assert np.array_equal(np.asarray(d["alphas_prev"]), g["ddim%d_alphas_prev" % steps])
+        assert np.array_equal(d["sigmas"].numpy(), g["ddim%d_sigmas" % steps])
+        assert np.array_equal(d["sqrt_one_minus_alphas"].numpy(), g["ddim%d_sqrt_one_minus_alphas" % steps])
+    assert np.array_equal(O.make_ddim_timesteps(50), 1 + 20 * np.arange(50))
+    assert np.array_equal(O.make_ddim_timesteps(10), 1 + 100 * np.arange(10))
+    d = O.ddim_schedule(s["alphas_cumprod"], 10, 0.7)
+    assert np.allclose(d["sigmas"].numpy(), g["ddim10_eta07_sigmas"], rtol=1e-6, atol=0)
+    with pytest.raises(IndexError):  # reference quirk: S=3 indexes alphas_cumprod[1000]
+        O.ddim_schedule(s["alphas_cumprod"], 3, 0.0)
+
+
+def test_timestep_embedding():
+    g = load("schedule.npz")
+    t = T(g["temb_t"])
+    assert np.array_equal(O.timestep_embedding(t, 320).numpy(), g["temb_320"])
+    assert np.array_equal(O.timestep_embedding(t, 64).numpy(), g["temb_64"])
+    e = O.timestep_embedding(torch.tensor([981]), 320)[0]
+    assert np.allclose(e[:3].numpy(), [0.67995721, -0.79842919, 0.57806414], atol=1e-6)
+    assert np.allclose(e[160:163].numpy(), [0.73325181, 0.60208869, 0.81599128], atol=1e-6)
+
+
+def test_unet_plan_matches_reference_structure(meta):
+    """Appendix A of SURVEY.md: the full-size 2D UNet has 30 data / 16 context blocks and 12 skips."""
+    p = O.unet_plan()
+    assert len(p["data"]) == 30 and len(p["ctx"]) == 16
+    assert p["i_order"].count("save_hidden_feature") == 12 and p["o_order"].count("load_hidden_feature") == 12
+    assert p["m_order"] == ["d", "c", "d"]
+    assert [c for c, _ in p["ctx"]] == [320, 320, 640, 640, 1280, 1280, 1280, 1280, 1280, 1280, 640, 640, 640, 320, 320, 320]
+    assert p["data"][14] == ("res", 2560, 1280) and p["data"][20] == ("res", 1920, 1280) and p["data"][26] == ("res", 960, 320)
+    tiny = O.unet_plan(**meta["unet2d"])
+    assert [h for _, h in tiny["ctx"]] == [1, 2, 2, 2, 2, 1, 1]
+
+
+def test_unet_tiny_forward(meta, tiny_sd):
+    g = load("unet_tiny.npz")
+    plan = O.unet_plan(**meta["unet2d"])
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        e_text = O.apply_model(tiny_sd, plan, x, t, T(g["c_text"]), c_type="text", global_ptr="image")
+        e_img = O.apply_model(tiny_sd, plan, x, t, T(g["c_img"]), c_type="image", global_ptr="image")
+        e_mix = O.apply_model_multicontext(tiny_sd, plan, x, t, [("text", T(g["c_text"]), 0.4), ("image", T(g["c_img"]), 0.6)])
+    assert rel(e_text, g["eps_text"]) < 1e-5
+    assert rel(e_img, g["eps_image"]) < 1e-5
+    assert rel(e_mix, g["eps_mix"]) < 1e-5
+    assert float(np.abs(g["eps_text"]).mean()) > 1e-2  # the synthetic weights do not zero the output
+
+
+def test_ddim_tiny(meta, tiny_sd):
+    g = load("ddim_tiny.npz")
+    plan = O.unet_plan(**meta["unet2d"])
+    ac = tiny_sd["alphas_cumprod"]
+    ctx_t = {"type": "text", "conditioning": T(g["c_text"]), "unconditional_conditioning": T(g["u_text"])}
+    ctx_i = {"type": "image", "conditioning": T(g["c_img"]), "unconditional_conditioning": T(g["u_img"])}
+    with torch.no_grad():
+        z, p0 = O.ddim_sample(tiny_sd, plan, ac, T(g["xT"]), [ctx_t], 5, 7.5, global_ptr="image")
+        assert rel(z, g["z_t2i"]) < 1e-4 and rel(p0, g["pred_x0_t2i"]) < 1e-4
+        zm, _ = O.ddim_sample(tiny_sd, plan, ac, T(g["xT"]), [dict(ctx_t, ratio=0.4), dict(ctx_i, ratio=0.6)], 4, 5.0)
+        assert rel(zm, g["z_mc"]) < 1e-4
+        sched = O.ddim_schedule(ac, 5)
+        ts = torch.full((2,), int(sched["timesteps"][3]), dtype=torch.long)
+        x_start = O.q_sample(tiny_sd, T(g["x0"]), ts, T(g["q_noise"]))
+        zi, _ = O.ddim_sample(tiny_sd, plan, ac, x_start, [ctx_i], 5, 1.0, forward_steps=3, global_ptr="image")
+        assert rel(zi, g["z_i2i"]) < 1e-4
+
+
+def test_vae_tiny(meta, tiny_sd):
+    g = load("vae_tiny.npz")
+    dd = meta["vae"]["ddconfig"]
+    kw = dict(ch_mult=dd["ch_mult"], num_res_blocks=dd["num_res_blocks"])
+    with torch.no_grad():
+        mom = O.vae_encode_moments(tiny_sd, "vae.image", T(g["img"]), **kw)
+        assert rel(mom, g["moments"]) < 1e-5
+        z = O.diag_gaussian_sample(mom, T(g["post_noise"])) * 0.18215
+        assert rel(z, g["z"]) < 1e-5
+        dec = O.vae_decode(tiny_sd, "vae.image", T(g["z"]) / 0.18215, **kw)
+        assert rel(dec, g["dec"]) < 1e-5
+        dec2 = O.vae_decode(tiny_sd, "vae.image", T(g["zlat"]) * (1.0 / 0.18215), **kw)
+        assert rel(dec2, g["dec2"]) < 1e-5
+
+
+def test_clip_tiny(meta):
+    from transformers import CLIPConfig, CLIPModel
+    g = load("clip_tiny.npz")
+    cfg = meta["clip"]
+    shapes = synth.shapes_of(CLIPModel(CLIPConfig(**cfg)))
+    sd = synth.synth_state_dict({"ctx.text.model." + k: v for k, v in shapes.items()}, meta["seed"])
+    tc, vc = cfg["text_config"], cfg["vision_config"]
+    ids = T(g["input_ids"])
+    px = torch.randn((3, 3, 224, 224), generator=torch.Generator().manual_seed(int(g["px_seed"])))
+    with torch.no_grad():
+        zt = O.clip_text_context(sd, "ctx.text.model", ids, tc["num_attention_heads"], tc["num_hidden_layers"])
+        assert rel(zt, g["z_text"]) < 1e-5
+        zi = O.clip_image_context(sd, "ctx.text.model", px, vc["num_attention_heads"], vc["num_hidden_layers"])
+        assert rel(zi, g["z_img"]) < 1e-5
+        vt, all_ones = O.clip_vtoken_mask(T(g["masks"]))
+        assert not all_ones
+        zm = O.clip_image_context(sd, "ctx.text.model", px, vc["num_attention_heads"], vc["num_hidden_layers"], vtoken_mask=vt)
+        assert rel(zm, g["z_img_masked"]) < 1e-5
