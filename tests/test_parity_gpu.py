@@ -1,0 +1,182 @@
+"""End-to-end parity of the HIP path (through the C ABI) against (1) the golden fixtures the reference produced
+and (2) the CPU fp32 oracle on full-width models.
+
+Tolerance: the path computes in fp16 with fp32 accumulation/statistics; BASELINE.json's north star bounds the
+final latents at <= 1e-2 relative L2 vs the fp32 reference.  Single forwards are held to 5e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from vdtest_util import full_vd_cfg, load_gold, meta, rel_l2, synth_into, tiny_vd_cfg
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 5e-3
+LATENT_TOL = 1e-2
+
+
+def T(a, dev, dtype=torch.float16):
+    return torch.from_numpy(np.asarray(a)).to(dev).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    from lib.model_zoo import get_model
+    m = meta()
+    net = get_model()(tiny_vd_cfg(m), verbose=False)
+    synth_into(net, m["seed"])
+    net = net.half()
+    net.to(dev)
+    return net
+
+
+def test_tiny_unet_vs_golden(tiny, dev):
+    g = load_gold("unet_tiny.npz")
+    x, t = T(g["x"], dev), torch.from_numpy(g["t"]).to(dev)
+    e = tiny.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": T(g["c_text"], dev)})
+    assert e.shape == x.shape and e.dtype == torch.float16
+    assert rel_l2(e, g["eps_text"]) < FWD_TOL
+    e = tiny.apply_model({"type": "image", "x": x}, t, {"type": "image", "c": T(g["c_img"], dev)})
+    assert rel_l2(e, g["eps_image"]) < FWD_TOL
+    e = tiny.apply_model_multicontext({"type": "image", "x": x}, t, [
+        {"type": "text", "c": T(g["c_text"], dev), "ratio": 0.4}, {"type": "image", "c": T(g["c_img"], dev), "ratio": 0.6}])
+    assert rel_l2(e, g["eps_mix"]) < FWD_TOL
+    # fp32 callers get fp32 back (compute stays fp16)
+    e32 = tiny.apply_model({"type": "image", "x": x.float()}, t, {"type": "text", "c": T(g["c_text"], dev, torch.float32)})
+    assert e32.dtype == torch.float32 and rel_l2(e32, g["eps_text"]) < FWD_TOL
+
+
+def test_tiny_ddim_vs_golden(tiny, dev, monkeypatch):
+    from lib.model_zoo.ddim import DDIMSampler
+    g = load_gold("ddim_tiny.npz")
+    sampler = DDIMSampler(tiny)
+    xT = T(g["xT"], dev)
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.clone())
+    ct = {"type": "text", "conditioning": T(g["c_text"], dev), "unconditional_conditioning": T(g["u_text"], dev),
+          "unconditional_guidance_scale": 7.5}
+    z, inter = sampler.sample(steps=5, shape=[2, 4, 16, 16], x_info={"type": "image"}, c_info=ct, eta=0., verbose=False)
+    assert rel_l2(z, g["z_t2i"]) < LATENT_TOL
+    assert rel_l2(inter["pred_x0"][-1], g["pred_x0_t2i"]) < LATENT_TOL
+    ci = {"type": "image", "conditioning": T(g["c_img"], dev), "unconditional_conditioning": T(g["u_img"], dev)}
+    zm, _ = sampler.sample_multicontext(steps=4, shape=[2, 4, 16, 16], x_info={"type": "image"}, c_info_list=[
+        dict(ct, unconditional_guidance_scale=5.0, ratio=0.4), dict(ci, unconditional_guidance_scale=5.0, ratio=0.6)],
+        eta=0., verbose=False)
+    assert rel_l2(zm, g["z_mc"]) < LATENT_TOL
+    monkeypatch.undo()
+    zi, _ = sampler.sample(steps=5, shape=[2, 4, 16, 16],
+                           x_info={"type": "image", "x0": T(g["x0"], dev), "x0_forward_timesteps": 3,
+                                   "x0_noise": T(g["q_noise"], dev)},
+                           c_info=dict(ci, unconditional_guidance_scale=1.0), eta=0., verbose=False)
+    assert rel_l2(zi, g["z_i2i"]) < LATENT_TOL
+
+
+def test_tiny_vae_vs_golden(tiny, dev):
+    g = load_gold("vae_tiny.npz")
+    img = T(g["img"], dev)
+    post = tiny.vae["image"].encode(img, out_posterior=True)
+    assert rel_l2(post.parameters, g["moments"]) < FWD_TOL
+    z = tiny.vae["image"].encode_scaled(img, 0.18215, noise=torch.from_numpy(g["post_noise"]))
+    assert rel_l2(z, g["z"]) < FWD_TOL
+    dec = tiny.vae_decode(T(g["z"], dev), which="image")
+    assert dec.shape == (2, 3, 32, 32) and float(dec.min()) >= 0 and float(dec.max()) <= 1
+    assert rel_l2(dec, g["dec"]) < FWD_TOL
+    assert rel_l2(tiny.vae_decode(T(g["zlat"], dev), which="image"), g["dec2"]) < FWD_TOL
+
+
+def test_tiny_clip_vs_golden(dev):
+    from lib.model_zoo.clip import CLIPImageContextEncoder, CLIPTextContextEncoder
+    from oracle import synth
+    m = meta()
+    g = load_gold("clip_tiny.npz")
+    tc, vc = m["clip"]["text_config"], m["clip"]["vision_config"]
+    cfg = dict(text={k: tc[k] for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers",
+                                        "num_attention_heads", "max_position_embeddings")},
+               vision={k: vc[k] for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                                          "image_size", "patch_size")}, projection_dim=m["clip"]["projection_dim"])
+    tenc = CLIPTextContextEncoder(config=cfg, fp16=True, max_length=24)
+    sd = synth.synth_state_dict({"ctx.text.model." + k: v for k, v in synth.shapes_of(tenc.model).items()}, m["seed"])
+    tenc.model.load_state_dict({k[len("ctx.text.model."):]: v for k, v in sd.items()}, strict=True)
+    tenc = tenc.half().to(dev)
+    z = tenc.encode(torch.from_numpy(g["input_ids"]))
+    assert rel_l2(z, g["z_text"]) < FWD_TOL
+    ienc = CLIPImageContextEncoder(config=cfg, fp16=True)
+    ienc.model.load_state_dict(tenc.model.state_dict())
+    ienc = ienc.half().to(dev)
+    px = torch.randn((3, 3, 224, 224), generator=torch.Generator().manual_seed(int(g["px_seed"])))
+    assert rel_l2(ienc.encode_pixels(px), g["z_img"]) < FWD_TOL
+    ts = ienc.vtoken_mask(torch.from_numpy(g["masks"]).to(dev))
+    assert ts is not None
+    assert rel_l2(ienc.encode_pixels(px, ts), g["z_img_masked"]) < FWD_TOL
+
+
+@pytest.fixture(scope="module")
+def full(dev):
+    from lib.model_zoo import get_model
+    net = get_model()(full_vd_cfg(with_vae=True), verbose=False)
+    sd = synth_into(net, 7)
+    net = net.half()
+    net.to(dev)
+    return net, sd
+
+
+def test_full_unet_forward_vs_oracle(full, dev):
+    """Full-width openai_unet_2d_v1 (859.5 M params) + text context blocks of the 0D net, 32x32 latent, CFG batch 2."""
+    from oracle import vd_oracle as O
+    net, sd = full
+    assert sum(p.numel() for p in net.diffuser["image"].parameters()) == 859520964
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 4, 32, 32), generator=g)
+    c = torch.randn((2, 77, 768), generator=g) * 0.5
+    t = torch.tensor([741, 741])
+    with torch.no_grad():
+        ref = O.apply_model(sd, O.unet_plan(), x, t, c, c_type="text", global_ptr="image")
+    e = net.apply_model({"type": "image", "x": x.half().to(dev)}, t.to(dev), {"type": "text", "c": c.half().to(dev)})
+    assert rel_l2(e, ref) < FWD_TOL
+    c2 = torch.randn((2, 257, 768), generator=g) * 0.5
+    with torch.no_grad():
+        ref2 = O.apply_model_multicontext(sd, O.unet_plan(), x, t, [("text", c, 0.5), ("image", c2, 0.5)])
+    e2 = net.apply_model_multicontext({"type": "image", "x": x.half().to(dev)}, t.to(dev), [
+        {"type": "text", "c": c.half().to(dev), "ratio": 0.5}, {"type": "image", "c": c2.half().to(dev), "ratio": 0.5}])
+    assert rel_l2(e2, ref2) < FWD_TOL
+
+
+def test_full_vae_vs_oracle(full, dev):
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn((1, 4, 32, 32), generator=g)
+    with torch.no_grad():
+        ref = O.vae_decode(sd, "vae.image", z / 0.18215)
+    dec = net.vae_decode(z.half().to(dev), which="image")
+    assert dec.shape == (1, 3, 256, 256)
+    assert rel_l2(dec, ref) < FWD_TOL
+    img = torch.rand((1, 3, 256, 256), generator=g)
+    nz = torch.randn((1, 4, 32, 32), generator=g)
+    with torch.no_grad():
+        zref = O.diag_gaussian_sample(O.vae_encode_moments(sd, "vae.image", img), nz) * 0.18215
+    zz = net.vae["image"].encode_scaled(img.half().to(dev), 0.18215, noise=nz)
+    assert rel_l2(zz, zref) < FWD_TOL
+
+
+def test_ddim_full_latent_parity(full, dev, monkeypatch):
+    """North-star bound: final latents after a guided DDIM loop within 1e-2 rel-L2 of the fp32 reference path
+    (full-width UNet, 16x16 latent to keep the CPU oracle in seconds, 6 steps, CFG 7.5)."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(11)
+    xT = torch.randn((1, 4, 16, 16), generator=g)
+    c = torch.randn((1, 77, 768), generator=g) * 0.5
+    u = torch.randn((1, 77, 768), generator=g) * 0.5
+    steps = 5
+    with torch.no_grad():
+        zref, _ = O.ddim_sample(sd, O.unet_plan(), sd["alphas_cumprod"], xT,
+                                [{"type": "text", "conditioning": c, "unconditional_conditioning": u}], steps, 7.5,
+                                global_ptr="image")
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.half().to(dev))
+    z, _ = DDIMSampler(net).sample(steps=steps, shape=[1, 4, 16, 16], x_info={"type": "image"},
+                                   c_info={"type": "text", "conditioning": c.half().to(dev),
+                                           "unconditional_conditioning": u.half().to(dev),
+                                           "unconditional_guidance_scale": 7.5}, eta=0., verbose=False)
+    assert rel_l2(z, zref) < LATENT_TOL

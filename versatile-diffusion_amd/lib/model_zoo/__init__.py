@@ -1,0 +1,1 @@
+from .common.get_model import get_model, register  # noqa: F401

@@ -1,0 +1,131 @@
+"""Transformer blocks of the VD UNet on the HIP kernel library, tokens-major (B*HW, C) end to end.
+
+Same module tree / state-dict keys as the reference (lib/model_zoo/attention.py:37-64,152-266 there), different
+execution: no NCHW<->(b, hw, c) transposes (the activation already is (B*HW, C)), q/k/v of the self-attention
+in ONE GEMM, scores never materialised (vd_attention_f16), residual adds / GEGLU gating / bias fused into GEMM
+epilogues, context K/V projections reusable across DDIM steps through an explicit cache.
+"""
+import torch
+import torch.nn as nn
+
+from vd_hip import ops, pack
+
+from .hip_layers import Conv2d, GroupNorm, LayerNorm, Linear, PackCache, _h
+
+
+class GEGLU(nn.Module, PackCache):
+    """proj: dim_in -> 2*dim_out, out = value * gelu(gate)  (reference attention.py:37-45), gating fused in the
+    GEMM epilogue; the weight rows are re-interleaved once so value/gate tiles meet in one workgroup."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        wp, bp = self._packed("geglu", (self.proj.weight, self.proj.bias),
+                              lambda: pack.pack_geglu(_h(self.proj.weight), _h(self.proj.bias)))
+        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=True, dropout=0.0):
+        super().__init__()
+        assert glu, "only the gated (GEGLU) feed-forward is on the VD path"
+        inner = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), Linear(inner, dim_out))
+
+    def forward(self, x, res=None):
+        return self.net[2](self.net[0](x), res=res)
+
+
+class CrossAttention(nn.Module, PackCache):
+    """softmax(q k^T d^-1/2) v with q from x and k, v from the context (x itself when context is None)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.inner = inner
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(context_dim, inner, bias=False)
+        self.to_v = Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(Linear(inner, query_dim), nn.Dropout(dropout))
+
+    def _w_qkv(self):
+        return self._packed("qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight),
+                            lambda: torch.cat([_h(self.to_q.weight), _h(self.to_k.weight), _h(self.to_v.weight)], 0))
+
+    def _w_kv(self):
+        return self._packed("kv", (self.to_k.weight, self.to_v.weight),
+                            lambda: torch.cat([_h(self.to_k.weight), _h(self.to_v.weight)], 0))
+
+    def project_context(self, context):
+        """[B, L, Dc] -> fused [B, L, 2*inner] (k | v); step-invariant for a fixed context."""
+        return ops.linear(context, self._w_kv())
+
+    def forward(self, x, context=None, res=None, kv=None):
+        """x [B, N, C] -> to_out(attn) (+ res fused)."""
+        c = self.inner
+        if context is None and kv is None:
+            qkv = ops.linear(x, self._w_qkv())
+            a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, scale=self.scale)
+        else:
+            if kv is None:
+                kv = self.project_context(context)
+            q = self.to_q(x)
+            a = ops.attention(q, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
+        return self.to_out[0](a, res=res)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False):
+        super().__init__()
+        assert not disable_self_attn
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+        self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
+
+    def forward(self, x, context=None, kv=None):
+        x = self.attn1(self.norm1(x), res=x)
+        x = self.attn2(self.norm2(x), context=context, res=x, kv=kv)
+        x = self.ff(self.norm3(x), res=x)
+        return x
+
+
+class SpatialTransformer(nn.Module):
+    """GroupNorm(eps 1e-6) -> 1x1 proj_in -> transformer block -> 1x1 proj_out -> + x_in, on [B, H, W, C]."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, disable_self_attn=False):
+        super().__init__()
+        assert depth == 1
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim,
+                                   disable_self_attn=disable_self_attn) for _ in range(depth)])
+        self.proj_out = Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
+        with torch.no_grad():  # zero_module(proj_out), reference attention.py:249-253
+            self.proj_out.weight.zero_()
+            self.proj_out.bias.zero_()
+
+    def project_context(self, context):
+        return self.transformer_blocks[0].attn2.project_context(context)
+
+    def forward(self, x, context=None, kv=None, alpha=1.0, res=None):
+        """Returns alpha * (proj_out(...) + bias) + res, res defaulting to x (the block's own skip).
+        alpha/res implement VD's context mixing sum_i r_i * ST_i(x) without extra passes."""
+        B, H, W, C = x.shape
+        h = self.proj_in(self.norm(x, silu=False))
+        h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv)
+        return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res)

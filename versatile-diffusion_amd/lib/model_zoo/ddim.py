@@ -1,0 +1,167 @@
+"""DDIM sampler with the reference's API (lib/model_zoo/ddim.py:10-298 there): `DDIMSampler(model).sample(...)`
+and `.sample_multicontext(...)` with the same arguments, dict protocol and return values.
+
+What changed underneath: the CFG combine and the DDIM update are ONE elementwise kernel fed with host-side
+schedule scalars (the reference issues ~10 tiny kernels and three device->host syncs per step), the CFG-doubled
+context batch is assembled once instead of every step, and the step-invariant context K/V projections of all 16
+cross-attention layers are computed once per sample() call and reused by every step.
+"""
+import numpy as np
+import torch
+
+from vd_hip import ops
+
+from .diffusion_utils import make_ddim_sampling_parameters, make_ddim_timesteps
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
+                                                  num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        if hasattr(self.model, "host_schedule"):
+            alphas_cumprod = self.model.host_schedule("alphas_cumprod")
+        else:
+            alphas_cumprod = self.model.alphas_cumprod.detach().float().cpu().numpy()
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        self.alphas_cumprod = alphas_cumprod
+        sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(
+            alphacums=alphas_cumprod, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
+        self.ddim_sigmas = np.asarray(sigmas, dtype=np.float32)
+        self.ddim_alphas = np.asarray(alphas, dtype=np.float32)
+        self.ddim_alphas_prev = np.asarray(alphas_prev, dtype=np.float64)
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(np.float32(1.) - self.ddim_alphas)
+
+    # ---- single context ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, steps, shape, x_info, c_info, eta=0., temperature=1., noise_dropout=0., verbose=True,
+               log_every_t=100):
+        self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
+        if verbose:
+            print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
+        return self.ddim_sampling_multicontext(shape, x_info, [c_info], noise_dropout=noise_dropout,
+                                               temperature=temperature, log_every_t=log_every_t, _single=True)
+
+    @torch.no_grad()
+    def ddim_sampling(self, shape, x_info, c_info, noise_dropout=0., temperature=1., log_every_t=100):
+        return self.ddim_sampling_multicontext(shape, x_info, [c_info], noise_dropout=noise_dropout,
+                                               temperature=temperature, log_every_t=log_every_t, _single=True)
+
+    # ---- multi context ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_multicontext(self, steps, shape, x_info, c_info_list, eta=0., temperature=1., noise_dropout=0.,
+                            verbose=True, log_every_t=100):
+        self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
+        if verbose:
+            print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
+        return self.ddim_sampling_multicontext(shape, x_info, c_info_list, noise_dropout=noise_dropout,
+                                               temperature=temperature, log_every_t=log_every_t)
+
+    @torch.no_grad()
+    def ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout=0., temperature=1.,
+                                   log_every_t=100, _single=False):
+        assert noise_dropout == 0., "noise_dropout is a training-time option"
+        device = self.model.device
+        dtype = c_info_list[0]["conditioning"].dtype
+        bs = shape[0]
+        timesteps = self.ddim_timesteps
+        if ("xt" in x_info) and (x_info["xt"] is not None):
+            x_info["x"] = x_info["xt"].to(device=device, dtype=dtype)
+        elif ("x0" in x_info) and (x_info["x0"] is not None):
+            x0 = x_info["x0"].to(device=device, dtype=dtype)
+            k = x_info["x0_forward_timesteps"]
+            ts = torch.full((bs,), int(timesteps[k]), device=device, dtype=torch.long)
+            timesteps = timesteps[:k]
+            # `x0_noise` (extension): inject the forward-process noise instead of drawing it, for reproducible runs
+            x_info["x"] = self.model.q_sample(x0, ts, noise=x_info.get("x0_noise"))
+        else:
+            x_info["x"] = torch.randn(shape, device=device, dtype=dtype)
+
+        scale = c_info_list[0]["unconditional_guidance_scale"]
+        for ci in c_info_list:
+            assert ci["unconditional_guidance_scale"] == scale, \
+                "A different unconditional guidance scale between different context is not allowed!"
+        guided = scale != 1.
+        # CFG batch [uncond ; cond] assembled ONCE; K/V projections of it cached for the whole loop
+        for ci in c_info_list:
+            if guided:
+                ci["c"] = torch.cat([ci["unconditional_conditioning"], ci["conditioning"]]).to(device)
+            else:
+                ci["c"] = ci["conditioning"].to(device)
+            ci["kv_cache"] = {}
+
+        intermediates = {"pred_xt": [], "pred_x0": []}
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        x = x_info["x"].to(torch.float16).contiguous()
+        pred_x0 = None
+        for i, step in enumerate(time_range):
+            index = total_steps - i - 1
+            x, pred_x0 = self._step(x, x_info, c_info_list, int(step), index, guided, scale, temperature, _single)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["pred_xt"].append(x.to(dtype))
+                intermediates["pred_x0"].append(pred_x0.to(dtype))
+        for ci in c_info_list:
+            ci.pop("kv_cache", None)
+        x_info["x"] = x.to(dtype)
+        return x_info["x"], intermediates
+
+    def _step(self, x, x_info, c_info_list, step, index, guided, scale, temperature, single):
+        """One p_sample_ddim (reference ddim.py:129-171 / 244-298) on the fp16 device latent `x` [B,C,H,W]."""
+        b = x.shape[0]
+        nb = 2 * b if guided else b
+        t_in = torch.full((nb,), step, device=x.device, dtype=torch.long)
+        x_in = torch.cat([x, x]) if guided else x
+        xi = {"type": x_info["type"], "x": x_in}
+        if single:
+            eps = self.model.apply_model(xi, t_in, c_info_list[0])
+        else:
+            eps = self.model.apply_model_multicontext(xi, t_in, c_info_list)
+        sigma = float(self.ddim_sigmas[index])
+        noise = None
+        if sigma != 0.:
+            noise = (torch.randn(x.shape, device=x.device, dtype=torch.float32) * temperature).to(torch.float16)
+        return ops.cfg_ddim_step(x, eps.contiguous(), guided=guided, guidance_scale=float(scale),
+                                 a_t=float(self.ddim_alphas[index]), a_prev=float(self.ddim_alphas_prev[index]),
+                                 sigma=sigma, sqrt_one_minus_at=float(self.ddim_sqrt_one_minus_alphas[index]),
+                                 noise=noise)
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x_info, c_info, t, index, repeat_noise=False, use_original_steps=False,
+                      noise_dropout=0., temperature=1.):
+        """Reference-compatible single step: returns (x_prev, pred_x0)."""
+        assert not use_original_steps and not repeat_noise
+        scale = c_info["unconditional_guidance_scale"]
+        guided = scale != 1.
+        ci = dict(c_info)
+        ci["c"] = torch.cat([c_info["unconditional_conditioning"], c_info["conditioning"]]) if guided else c_info["conditioning"]
+        x = x_info["x"]
+        xp, p0 = self._step(x.to(torch.float16).contiguous(), x_info, [ci], int(t[0]), index, guided, scale,
+                            temperature, True)
+        return xp.to(x.dtype), p0.to(x.dtype)
+
+    @torch.no_grad()
+    def p_sample_ddim_multicontext(self, x_info, c_info_list, t, index, repeat_noise=False, use_original_steps=False,
+                                   noise_dropout=0., temperature=1.):
+        assert not use_original_steps and not repeat_noise
+        scale = c_info_list[0]["unconditional_guidance_scale"]
+        guided = scale != 1.
+        cis = []
+        for c_info in c_info_list:
+            assert c_info["unconditional_guidance_scale"] == scale
+            ci = dict(c_info)
+            ci["c"] = torch.cat([c_info["unconditional_conditioning"], c_info["conditioning"]]) if guided else c_info["conditioning"]
+            cis.append(ci)
+        x = x_info["x"]
+        xp, p0 = self._step(x.to(torch.float16).contiguous(), x_info, cis, int(t[0]), index, guided, scale,
+                            temperature, False)
+        return xp.to(x.dtype), p0.to(x.dtype)

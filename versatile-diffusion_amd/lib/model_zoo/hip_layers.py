@@ -1,0 +1,108 @@
+"""Channels-last layer primitives that run on the HIP kernel library (vd_hip).
+
+Every class subclasses the torch module the reference uses in the same slot (nn.Conv2d, nn.Linear,
+nn.GroupNorm, nn.LayerNorm) so parameter names, shapes, initialisation and state-dict keys are identical to
+the reference checkpoints -- but `forward` never touches a torch arithmetic op: it re-lays the weights out once
+(cached, keyed on the parameter's storage/version) and enqueues vd_hip kernels.  Activations are fp16
+[B, H, W, C] (== (B*H*W, C) row-major) throughout; there is no CPU or eager fallback.
+"""
+import torch
+import torch.nn as nn
+
+from vd_hip import ops, pack
+
+
+def _ver(t):
+    return None if t is None else (t.data_ptr(), t._version, t.dtype, str(t.device), tuple(t.shape))
+
+
+class PackCache:
+    """Mixin: cache of kernel-layout fp16 copies of parameters, rebuilt when the parameter storage changes
+    (load_state_dict, .half(), .to(device))."""
+
+    def _packed(self, key, tensors, fn):
+        cache = self.__dict__.setdefault("_vd_pack_cache", {})
+        ver = tuple(_ver(t) for t in tensors)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                val = fn()
+            cache[key] = (ver, val)
+            return val
+        return hit[1]
+
+
+def _h(t):
+    """fp16 contiguous device copy/view of a parameter (compute dtype of the path is fp16)."""
+    return None if t is None else t.detach().to(torch.float16).contiguous()
+
+
+class Conv2d(nn.Conv2d, PackCache):
+    """3x3 / 1x1 convolution as implicit GEMM on channels-last input (vd_gemm_f16).
+
+    forward(x, x1=None, ups=0, pad_hi=None, **epilogue): x1 is an optional second tensor whose channels are
+    concatenated after x's (never materialised); ups=1 fuses a nearest 2x upsample in front; epilogue keywords
+    (rowvec/rows_per_batch/res/act/alpha) are fused into the GEMM epilogue."""
+
+    def _w(self):
+        def build():
+            w = _h(self.weight)
+            cin = w.shape[1]
+            if cin % 64 != 0:  # small-Cin path goes through vd_im2col_small_f16
+                return pack.pack_conv_weight_small(w), _h(self.bias)
+            return pack.pack_conv_weight(w), _h(self.bias)
+        return self._packed("w", (self.weight, self.bias), build)
+
+    def forward(self, x, x1=None, ups=0, pad_hi=None, in_layout="nhwc", in_scale=1.0, in_shift=0.0, **epi):
+        w, b = self._w()
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        cin = self.in_channels
+        if cin % 64 != 0:
+            assert x1 is None and ups == 0
+            a, (B, Ho, Wo) = ops.im2col_small(x, layout=in_layout, ksize=k, stride=s, pad=p, pad_hi=pad_hi,
+                                              in_scale=in_scale, in_shift=in_shift)
+            out = ops.gemm(a, w, bias=b, **epi)
+            return out.view(B, Ho, Wo, self.out_channels)
+        assert in_layout == "nhwc" and in_scale == 1.0 and in_shift == 0.0
+        return ops.conv2d_nhwc(x, w, b, ksize=k, stride=s, pad=p, ups=ups, x1=x1, pad_hi=pad_hi, **epi)
+
+
+class Linear(nn.Linear, PackCache):
+    def _w(self):
+        return self._packed("w", (self.weight, self.bias), lambda: (_h(self.weight), _h(self.bias)))
+
+    def forward(self, x, **epi):
+        w, b = self._w()
+        return ops.linear(x, w, b, **epi)
+
+
+class GroupNorm(nn.GroupNorm, PackCache):
+    """GroupNorm over channels-last input, optionally over cat([x, x1]) and fused with SiLU."""
+
+    def _w(self):
+        return self._packed("w", (self.weight, self.bias), lambda: (_h(self.weight), _h(self.bias)))
+
+    def forward(self, x, x1=None, silu=False):
+        g, b = self._w()
+        return ops.groupnorm_silu(x, g, b, x1=x1, groups=self.num_groups, eps=self.eps, silu=silu)
+
+
+class LayerNorm(nn.LayerNorm, PackCache):
+    def _w(self):
+        return self._packed("w", (self.weight, self.bias), lambda: (_h(self.weight), _h(self.bias)))
+
+    def forward(self, x):
+        g, b = self._w()
+        return ops.layernorm(x, g, b, self.eps)
+
+
+class SiLU(nn.Module):
+    """Placeholder keeping nn.Sequential indices identical to the reference; the activation itself is always
+    fused into the neighbouring kernel (GroupNorm+SiLU, GEMM epilogue)."""
+
+    def forward(self, x):
+        raise RuntimeError("SiLU is fused into the adjacent HIP kernel; this module is never called directly")
+
+
+class Identity(nn.Identity):
+    pass

@@ -1,0 +1,391 @@
+"""UNet of the Versatile-Diffusion image flow on the HIP kernel library.
+
+Registry names, constructor arguments, attribute names and state-dict keys follow the reference
+(lib/model_zoo/openaimodel.py there: ResBlock :162-274, Upsample :89-117, Downsample :133-159,
+TimestepEmbedSequential :72-86, UNetModel2D_Next :2575-2812, UNetModel0D_Next :2814-2975), so
+`get_model()(model_cfg_bank()('openai_unet_2d_v1'))` and reference checkpoints work unchanged.  The execution is
+new: channels-last fp16 activations, GroupNorm+SiLU in one pass, 3x3 convs as implicit MFMA GEMMs that read the
+skip-connection concat / nearest-2x upsample in place and fold bias, the timestep-embedding broadcast and the
+residual add into their epilogue.
+"""
+import copy
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vd_hip import ops
+
+from .attention import SpatialTransformer
+from .common.get_model import register
+from .diffusion_utils import timestep_embedding  # noqa: F401  (re-exported like the reference does)
+from .hip_layers import Conv2d, GroupNorm, Linear, PackCache, SiLU, _h
+
+symbol = "openai"
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class TimestepBlock(nn.Module):
+    """Marker: forward(x, emb) takes the timestep embedding."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Dispatches (x, emb, context) to its single child by type, like the reference; additionally threads the
+    channels-last extras: `skip` (tensor concatenated on channels in place), the context K/V cache and the
+    mixing epilogue."""
+
+    def forward(self, x, emb, context=None, skip=None, **ctx_kw):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb, skip=skip)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context, **ctx_kw)
+            elif isinstance(layer, OutputHead):
+                x = layer(x)
+            else:
+                x = layer(x)
+            skip = None
+        return x
+
+
+class TimeEmbed(nn.Sequential, PackCache):
+    """Linear -> SiLU -> Linear (reference openaimodel.py:2627-2633).  `forward_silu` returns SiLU(emb), which is
+    what every consumer (ResBlock.emb_layers) actually reads, with both activations fused in GEMM epilogues."""
+
+    def __init__(self, model_channels, time_embed_dim):
+        super().__init__(Linear(model_channels, time_embed_dim), SiLU(), Linear(time_embed_dim, time_embed_dim))
+
+    def forward(self, t_emb):
+        return self[2](self[0](t_emb, act=ops.ACT_SILU))
+
+    def forward_silu(self, t_emb):
+        return self[2](self[0](t_emb, act=ops.ACT_SILU), act=ops.ACT_SILU)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.conv = Conv2d(self.channels, self.out_channels, 3, padding=padding)
+
+    def forward(self, x):
+        return self.conv(x, ups=1)  # nearest 2x folded into the conv's gather
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.op = Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class ResBlock(TimestepBlock):
+    """GN+SiLU -> conv3x3 (+bias +emb) -> GN+SiLU -> conv3x3 (+bias +skip(x)); use_scale_shift_norm=False."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        assert dims == 2 and not use_scale_shift_norm and not up and not down and not use_conv
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.use_checkpoint = use_checkpoint
+        self.in_layers = nn.Sequential(GroupNorm(32, channels), SiLU(), Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(SiLU(), Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(GroupNorm(32, self.out_channels), SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = Conv2d(channels, self.out_channels, 1)
+
+    def forward(self, x, emb_silu, skip=None):
+        """x [B,H,W,C0] (++ skip [B,H,W,C1] on channels); emb_silu = SiLU(time embedding) [B, emb_channels]."""
+        B, H, W, _ = x.shape
+        emb_out = self.emb_layers[1](emb_silu)
+        h = self.in_layers[0](x, x1=skip, silu=True)
+        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W)
+        h = self.out_layers[0](h, silu=True)
+        if isinstance(self.skip_connection, nn.Identity):
+            assert skip is None
+            res = x
+        else:
+            res = self.skip_connection(x, x1=skip)
+        return self.out_layers[3](h, res=res)
+
+
+class OutputHead(nn.Sequential):
+    """normalization -> SiLU -> zero conv3x3 (reference openaimodel.py:2732-2737)."""
+
+    def __init__(self, ch, out_channels):
+        super().__init__(GroupNorm(32, ch), SiLU(), zero_module(Conv2d(ch, out_channels, 3, padding=1)))
+
+    def forward(self, x):
+        return self[2](self[0](x, silu=True))
+
+
+class InputConv(Conv2d):
+    """First data layer: 3x3 conv on the NCHW latent the sampler hands over (small-Cin im2col + MFMA GEMM)."""
+
+    def forward(self, x):
+        return super().forward(x, in_layout="nchw")
+
+
+@register("openai_unet_2d_next")
+class UNetModel2D_Next(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, context_dim,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, use_checkpoint=False, num_heads=8,
+                 num_head_channels=None, parts=("global", "data", "context")):
+        super().__init__()
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        if isinstance(num_res_blocks, int):
+            self.num_res_blocks = len(channel_mult) * [num_res_blocks]
+        else:
+            if len(num_res_blocks) != len(channel_mult):
+                raise ValueError("provide num_res_blocks either as an int (globally constant) or "
+                                 "as a list/tuple (per-level) with the same length as channel_mult")
+            self.num_res_blocks = list(num_res_blocks)
+        self.attention_resolutions = attention_resolutions
+        self.context_dim = context_dim
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.use_checkpoint = use_checkpoint
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        assert (num_heads is None) + (num_head_channels is None) == 1, \
+            "One of num_heads or num_head_channels need to be set"
+        self._init_parts(parts, model_channels)
+
+        time_embed_dim = model_channels * 4
+        res = partial(ResBlock, emb_channels=time_embed_dim, dropout=dropout, dims=2, use_checkpoint=use_checkpoint,
+                      use_scale_shift_norm=False) if self.dlayer_included else (lambda **kw: None)
+        xattn = partial(SpatialTransformer, context_dim=context_dim, disable_self_attn=False) \
+            if self.clayer_included else (lambda **kw: None)
+
+        self.add_data_layer(InputConv(in_channels, model_channels, 3, padding=1) if self.dlayer_included else None)
+        self.layer_sequence_ordering.append("save_hidden_feature")
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                self.add_data_layer(res(channels=ch, out_channels=mult * model_channels))
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    d_head, n_heads = self.get_d_head_n_heads(ch)
+                    self.add_context_layer(xattn(in_channels=ch, d_head=d_head, n_heads=n_heads))
+                input_block_chans.append(ch)
+                self.layer_sequence_ordering.append("save_hidden_feature")
+            if level != len(channel_mult) - 1:
+                self.add_data_layer(Downsample(ch, use_conv=True, dims=2, out_channels=ch) if self.dlayer_included else None)
+                input_block_chans.append(ch)
+                self.layer_sequence_ordering.append("save_hidden_feature")
+                ds *= 2
+        self.i_order = copy.deepcopy(self.layer_sequence_ordering)
+        self.layer_sequence_ordering = []
+
+        self.add_data_layer(res(channels=ch))
+        d_head, n_heads = self.get_d_head_n_heads(ch)
+        self.add_context_layer(xattn(in_channels=ch, d_head=d_head, n_heads=n_heads))
+        self.add_data_layer(res(channels=ch))
+        self.m_order = copy.deepcopy(self.layer_sequence_ordering)
+        self.layer_sequence_ordering = []
+
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for _ in range(self.num_res_blocks[level] + 1):
+                self.layer_sequence_ordering.append("load_hidden_feature")
+                ich = input_block_chans.pop()
+                self.add_data_layer(res(channels=ch + ich, out_channels=model_channels * mult))
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    d_head, n_heads = self.get_d_head_n_heads(ch)
+                    self.add_context_layer(xattn(in_channels=ch, d_head=d_head, n_heads=n_heads))
+            if level != 0:
+                self.add_data_layer(Upsample(ch, conv_resample, dims=2, out_channels=ch) if self.dlayer_included else None)
+                ds //= 2
+        self.add_data_layer(OutputHead(ch, out_channels) if self.dlayer_included else None)
+        self._finish_orders()
+
+    # ---- shared bookkeeping (2D and 0D nets) -------------------------------------------------
+    def _init_parts(self, parts, model_channels):
+        self.parts = list(parts) if isinstance(parts, (list, tuple)) else [parts]
+        self.glayer_included = "global" in self.parts
+        self.dlayer_included = "data" in self.parts
+        self.clayer_included = "context" in self.parts
+        self.layer_sequence_ordering = []
+        if self.glayer_included:
+            self.time_embed = TimeEmbed(model_channels, model_channels * 4)
+        if self.dlayer_included:
+            self.data_blocks = nn.ModuleList([])
+        if self.clayer_included:
+            self.context_blocks = nn.ModuleList([])
+
+    def _finish_orders(self):
+        self.o_order = copy.deepcopy(self.layer_sequence_ordering)
+        self.layer_order = copy.deepcopy(self.i_order + self.m_order + self.o_order)
+        del self.layer_sequence_ordering
+        self.parameter_group = {}
+        if self.glayer_included:
+            self.parameter_group["global"] = self.time_embed
+        if self.dlayer_included:
+            self.parameter_group["data"] = self.data_blocks
+        if self.clayer_included:
+            self.parameter_group["context"] = self.context_blocks
+
+    def get_d_head_n_heads(self, ch):
+        if self.num_head_channels is None:
+            return ch // self.num_heads, self.num_heads
+        return self.num_head_channels, ch // self.num_head_channels
+
+    def add_data_layer(self, layer):
+        if self.dlayer_included:
+            layers = list(layer) if isinstance(layer, (list, tuple)) else [layer]
+            self.data_blocks.append(TimestepEmbedSequential(*layers))
+        self.layer_sequence_ordering.append("d")
+
+    def add_context_layer(self, layer):
+        if self.clayer_included:
+            layers = list(layer) if isinstance(layer, (list, tuple)) else [layer]
+            self.context_blocks.append(TimestepEmbedSequential(*layers))
+        self.layer_sequence_ordering.append("c")
+
+    def forward(self, x, timesteps, context):
+        """Stand-alone forward (NCHW in / NCHW out).  The reference's own .forward walks i_order twice (a bug,
+        openaimodel.py:2801) and is never used by VD_v2_0; this one walks o_order as VD_v2_0.apply_model does."""
+        from .vd import run_unet
+        emb = self.time_embed.forward_silu(timestep_embedding(timesteps, self.model_channels))
+        return run_unet(self, [(self.context_blocks, context, 1.0, None)], x, emb)
+
+
+class Linear_MultiDim(nn.Linear):
+    """Parameter container for the 0-D (text-latent) data flow; same keys/shapes as the reference
+    (openaimodel.py:2275-2293).  The text *data* flow is outside this package's hot path."""
+
+    def __init__(self, in_features, out_features, *args, **kwargs):
+        in_features = [in_features] if isinstance(in_features, int) else list(in_features)
+        out_features = [out_features] if isinstance(out_features, int) else list(out_features)
+        self.in_features_multidim = in_features
+        self.out_features_multidim = out_features
+        super().__init__(int(np.prod(in_features)), int(np.prod(out_features)), *args, **kwargs)
+
+    def forward(self, x):
+        raise NotImplementedError("text-latent data flow (UNetModel0D data blocks) is not on the image sampling path")
+
+
+class FCBlock_MultiDim(TimestepBlock):
+    """Parameter container, keys as reference FCBlock/FCBlock_MultiDim (openaimodel.py:2084-2141,2295-2332)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_checkpoint=False):
+        super().__init__()
+        channels = [channels] if isinstance(channels, int) else list(channels)
+        c_all = int(np.prod(channels))
+        if out_channels is not None:
+            out_channels = [out_channels] if isinstance(out_channels, int) else list(out_channels)
+            o_all = int(np.prod(out_channels))
+        else:
+            out_channels, o_all = channels, c_all
+        self.channels_multidim, self.out_channels_multidim = channels, out_channels
+        self.channels, self.out_channels, self.emb_channels = c_all, o_all, emb_channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, c_all), nn.SiLU(), nn.Conv2d(c_all, o_all, 1, padding=0))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, o_all))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, o_all), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(o_all, o_all, 1, padding=0)))
+        self.skip_connection = nn.Identity() if o_all == c_all else nn.Conv2d(c_all, o_all, 1, padding=0)
+
+    def forward(self, x, emb, skip=None):
+        raise NotImplementedError("text-latent data flow (UNetModel0D data blocks) is not on the image sampling path")
+
+
+@register("openai_unet_0d_next")
+class UNetModel0D_Next(UNetModel2D_Next):
+    """The 'text' diffuser of vd_four_flow: its *context* blocks (SpatialTransformers conditioned on CLIP text)
+    are what the image flow uses for text-to-image (vd.py:345 in the reference); its data blocks only hold
+    parameters here."""
+
+    def __init__(self, input_channels, model_channels, output_channels, context_dim=788, num_noattn_blocks=(2, 2, 2, 2),
+                 channel_mult=(1, 2, 4, 8), second_dim=(4, 4, 4, 4), with_attn=(True, True, True, False), num_heads=8,
+                 num_head_channels=None, use_checkpoint=False, parts=("global", "data", "context")):
+        nn.Module.__init__(self)
+        self.input_channels = input_channels
+        self.model_channels = model_channels
+        self.output_channels = output_channels
+        self.num_noattn_blocks = num_noattn_blocks
+        self.channel_mult = channel_mult
+        self.second_dim = second_dim
+        self.with_attn = with_attn
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self._init_parts(parts, model_channels)
+        time_embed_dim = model_channels * 4
+        fc = partial(FCBlock_MultiDim, dropout=0, use_checkpoint=use_checkpoint) if self.dlayer_included \
+            else (lambda *a, **kw: None)
+        lin = Linear_MultiDim if self.dlayer_included else (lambda *a, **kw: None)
+        xattn = partial(SpatialTransformer, context_dim=context_dim, disable_self_attn=False) \
+            if self.clayer_included else (lambda **kw: None)
+
+        cur = [model_channels, second_dim[0], 1]
+        self.add_data_layer(lin([input_channels], cur, bias=True))
+        self.layer_sequence_ordering.append("save_hidden_feature")
+        chans = [cur]
+        for level, (mult, sdim) in enumerate(zip(channel_mult, second_dim)):
+            for _ in range(num_noattn_blocks[level]):
+                self.add_data_layer(fc(cur, time_embed_dim, out_channels=[mult * model_channels, sdim, 1]))
+                cur = [mult * model_channels, sdim, 1]
+                if with_attn[level]:
+                    d_head, n_heads = self.get_d_head_n_heads(cur[0])
+                    self.add_context_layer(xattn(in_channels=cur[0], d_head=d_head, n_heads=n_heads))
+                chans.append(cur)
+                self.layer_sequence_ordering.append("save_hidden_feature")
+            if level != len(channel_mult) - 1:
+                self.add_data_layer(lin(cur, cur, bias=True))
+                chans.append(cur)
+                self.layer_sequence_ordering.append("save_hidden_feature")
+        self.i_order = copy.deepcopy(self.layer_sequence_ordering)
+        self.layer_sequence_ordering = []
+
+        self.add_data_layer(fc(cur, time_embed_dim))
+        d_head, n_heads = self.get_d_head_n_heads(cur[0])
+        self.add_context_layer(xattn(in_channels=cur[0], d_head=d_head, n_heads=n_heads))
+        self.add_data_layer(fc(cur, time_embed_dim))
+        self.m_order = copy.deepcopy(self.layer_sequence_ordering)
+        self.layer_sequence_ordering = []
+
+        for level, (mult, sdim) in list(enumerate(zip(channel_mult, second_dim)))[::-1]:
+            for _ in range(num_noattn_blocks[level] + 1):
+                self.layer_sequence_ordering.append("load_hidden_feature")
+                extra = chans.pop()
+                self.add_data_layer(fc([cur[0] + extra[0]] + cur[1:], time_embed_dim,
+                                       out_channels=[mult * model_channels, sdim, 1]))
+                cur = [mult * model_channels, sdim, 1]
+                if with_attn[level]:
+                    d_head, n_heads = self.get_d_head_n_heads(cur[0])
+                    self.add_context_layer(xattn(in_channels=cur[0], d_head=d_head, n_heads=n_heads))
+            if level != 0:
+                self.add_data_layer(lin(cur, cur, bias=True))
+        if self.dlayer_included:
+            head = nn.Sequential(nn.GroupNorm(32, cur[0]), nn.SiLU(), zero_module(Linear_MultiDim(cur, [output_channels], bias=True)))
+        else:
+            head = None
+        self.add_data_layer(head)
+        self._finish_orders()
+
+    def forward(self, *a, **kw):
+        raise NotImplementedError("UNetModel0D_Next only contributes context blocks to the image sampling path")

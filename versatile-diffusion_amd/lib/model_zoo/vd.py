@@ -1,0 +1,240 @@
+"""VD_v2_0: the multi-flow container (VAEs, context encoders, diffusers + DDPM schedule) behind the reference's
+model contract (lib/model_zoo/vd.py:41-455 there): `ctx_encode`, `vae_encode`, `vae_decode`, `apply_model`,
+`apply_model_multicontext`, `q_sample`, the 12 schedule buffers, `.to()` semantics and the state-dict layout.
+
+Execution differs from the reference: `apply_model*` converts nothing to NCHW in between -- the latent enters the
+first conv straight from NCHW, every block runs channels-last fp16 on HIP kernels, skip connections are read in
+place (no torch.cat), context mixing is folded into the proj_out epilogues, and the step-invariant context K/V
+projections can be cached across DDIM steps (`c_info['kv_cache']`, set up by DDIMSampler).
+"""
+from functools import partial
+
+import numpy as np
+import numpy.random as npr
+import torch
+import torch.nn as nn
+
+from vd_hip import ops
+
+from ..log_service import print_log
+from .common.get_model import get_model, register
+from .diffusion_utils import extract_into_tensor, make_beta_schedule, timestep_embedding
+
+symbol = "vd"
+
+
+class String_Reg_Buffer(nn.Module):
+    """A config entry given as a plain string is kept as a byte buffer (reference vd.py:28-39)."""
+
+    def __init__(self, output_string):
+        super().__init__()
+        self.register_buffer("output_string", torch.ByteTensor(list(bytes(output_string, "utf8"))))
+
+    @torch.no_grad()
+    def forward(self, *args, **kwargs):
+        return bytes(self.output_string.tolist()).decode()
+
+
+def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
+    """Walk i/m/o orders of `data_net` (reference vd.py:352-378 / 429-453).
+
+    ctx_specs: list of (context_blocks, context [B, L, Dc], ratio, kv_cache or None), one per context type.
+    x: NCHW latent; returns NCHW eps in fp16."""
+    d_iter = iter(data_net.data_blocks)
+    c_iters = [iter(spec[0]) for spec in ctx_specs]
+    ratios = np.array([float(spec[2]) for spec in ctx_specs], dtype=np.float64)
+    ratios = ratios / ratios.sum()
+    hs = []
+
+    def run_context(h):
+        modules = [next(it) for it in c_iters]
+        if mixing_type == "layer":
+            pick = int(npr.choice(len(modules), p=ratios))
+            modules, specs, rs = [modules[pick]], [ctx_specs[pick]], [1.0]
+        else:
+            specs, rs = ctx_specs, ratios
+        out = None
+        single = len(modules) == 1
+        for module, spec, r in zip(modules, specs, rs):
+            _, c, _, cache = spec
+            kv = None
+            if cache is not None:
+                kv = cache.get(id(module))
+                if kv is None:
+                    kv = module[0].project_context(c)
+                    cache[id(module)] = kv
+            # h_out = sum_i r_i * ST_i(h) = sum_i r_i * proj_i + h   (sum r_i = 1): chained through the epilogue
+            out = module(h, None, c, kv=kv, alpha=1.0 if single else float(r), res=out)
+        return out
+
+    h = x
+    for ltype in data_net.i_order + data_net.m_order:
+        if ltype == "d":
+            h = next(d_iter)(h, emb_silu, None)
+        elif ltype == "c":
+            h = run_context(h)
+        elif ltype == "save_hidden_feature":
+            hs.append(h)
+    skip = None
+    for ltype in data_net.o_order:
+        if ltype == "load_hidden_feature":
+            skip = hs.pop()
+        elif ltype == "d":
+            h = next(d_iter)(h, emb_silu, None, skip=skip)
+            skip = None
+        elif ltype == "c":
+            h = run_context(h)
+    return ops.nhwc_to_nchw(h)
+
+
+@register("vd_v2_0")
+class VD_v2_0(nn.Module):
+    def __init__(self, vae_cfg_list, ctx_cfg_list, diffuser_cfg_list, global_layer_ptr=None, parameterization="eps",
+                 timesteps=1000, use_ema=False, beta_schedule="linear", beta_linear_start=1e-4, beta_linear_end=2e-2,
+                 given_betas=None, cosine_s=8e-3, loss_type="l2", l_simple_weight=1., l_elbo_weight=0.,
+                 v_posterior=0., learn_logvar=False, logvar_init=0, latent_scale_factor=None):
+        super().__init__()
+        assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
+        assert not use_ema, "EMA is a training feature (the reference itself cannot enable it, vd.py:84)"
+        self.parameterization = parameterization
+        print_log("Running in {} mode".format(parameterization))
+        self.vae = self.get_model_list(vae_cfg_list)
+        self.ctx = self.get_model_list(ctx_cfg_list)
+        self.diffuser = self.get_model_list(diffuser_cfg_list)
+        self.global_layer_ptr = global_layer_ptr
+        assert self.check_diffuser(), "diffuser layers are not aligned!"
+        self.use_ema = use_ema
+        self.loss_type, self.l_simple_weight, self.l_elbo_weight = loss_type, l_simple_weight, l_elbo_weight
+        self.v_posterior = v_posterior
+        self.device = "cpu"
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=beta_linear_start, linear_end=beta_linear_end, cosine_s=cosine_s)
+        self.learn_logvar = learn_logvar
+        self.logvar = torch.full(fill_value=logvar_init, size=(self.num_timesteps,))
+        self.latent_scale_factor = {} if latent_scale_factor is None else dict(latent_scale_factor)
+        self.parameter_group = {}
+        for namei, diffuseri in self.diffuser.items():
+            self.parameter_group.update({"diffuser_{}_{}".format(namei, pgni): pgi
+                                         for pgni, pgi in diffuseri.parameter_group.items()})
+
+    def to(self, device):
+        # reference quirk kept on purpose: returns None and records the device (vd.py:114-116)
+        self.device = device
+        super().to(device)
+
+    def get_model_list(self, cfg_list):
+        net = nn.ModuleDict()
+        for name, cfg in cfg_list:
+            net[name] = String_Reg_Buffer(cfg) if isinstance(cfg, str) else get_model()(cfg)
+        return net
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        alphas = 1. - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.linear_start, self.linear_end = linear_start, linear_end
+        assert alphas_cumprod.shape[0] == self.num_timesteps, "alphas have to be defined for each timestep"
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        reg = lambda name, arr: self.register_buffer(name, to_torch(arr))
+        reg("betas", betas)
+        reg("alphas_cumprod", alphas_cumprod)
+        reg("alphas_cumprod_prev", alphas_cumprod_prev)
+        reg("sqrt_alphas_cumprod", np.sqrt(alphas_cumprod))
+        reg("sqrt_one_minus_alphas_cumprod", np.sqrt(1. - alphas_cumprod))
+        reg("log_one_minus_alphas_cumprod", np.log(1. - alphas_cumprod))
+        reg("sqrt_recip_alphas_cumprod", np.sqrt(1. / alphas_cumprod))
+        reg("sqrt_recipm1_alphas_cumprod", np.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = (1 - self.v_posterior) * betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod) \
+            + self.v_posterior * betas
+        reg("posterior_variance", posterior_variance)
+        reg("posterior_log_variance_clipped", np.log(np.maximum(posterior_variance, 1e-20)))
+        reg("posterior_mean_coef1", betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        reg("posterior_mean_coef2", (1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod))
+        # host copies in float32: the sampler reads schedule scalars without a device sync
+        self._host_schedule = {"alphas_cumprod": alphas_cumprod.astype(np.float32),
+                               "sqrt_alphas_cumprod": np.sqrt(alphas_cumprod).astype(np.float32),
+                               "sqrt_one_minus_alphas_cumprod": np.sqrt(1. - alphas_cumprod).astype(np.float32)}
+
+    def host_schedule(self, name):
+        """fp32 host copy of a schedule buffer (re-derived from the buffer if a checkpoint overwrote it)."""
+        return self._host_schedule[name]
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        for name in list(self._host_schedule):
+            if prefix + name in state_dict:
+                self._host_schedule[name] = state_dict[prefix + name].detach().float().cpu().numpy()
+
+    def check_diffuser(self):
+        orders = [d.layer_order for d in self.diffuser.values()]
+        return all(o == orders[0] for o in orders)
+
+    # ---- q(x_t | x_0) ----------------------------------------------------------------------------
+    def q_sample(self, x_start, t, noise=None):
+        """sqrt(acp_t) x0 + sqrt(1 - acp_t) noise (reference vd.py:221-224); fp16 in / fp16 out on the device."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        sa = extract_into_tensor(self.sqrt_alphas_cumprod, t, (t.shape[0],)).float().contiguous()
+        sb = extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, (t.shape[0],)).float().contiguous()
+        dt = x_start.dtype
+        out = ops.q_sample(x_start.to(torch.float16).contiguous(), noise.to(torch.float16).contiguous(), sa.view(-1), sb.view(-1))
+        return out.to(dt)
+
+    # ---- VAE / context encoders --------------------------------------------------------------------
+    @torch.no_grad()
+    def vae_encode(self, x, which, **kwargs):
+        scale = (self.latent_scale_factor or {}).get(which, None)
+        if scale is not None and hasattr(self.vae[which], "encode_scaled"):
+            return self.vae[which].encode_scaled(x, scale=scale, **kwargs)
+        z = self.vae[which].encode(x, **kwargs)
+        return z if scale is None else scale * z
+
+    @torch.no_grad()
+    def vae_decode(self, z, which, **kwargs):
+        scale = (self.latent_scale_factor or {}).get(which, None)
+        if scale is not None and hasattr(self.vae[which], "decode_scaled"):
+            return self.vae[which].decode_scaled(z, inv_scale=1. / scale, **kwargs)
+        if scale is not None:
+            z = 1. / scale * z
+        return self.vae[which].decode(z, **kwargs)
+
+    @torch.no_grad()
+    def ctx_encode(self, x, which, **kwargs):
+        if which.find("vae_") == 0:
+            return self.vae[which[4:]].encode(x, **kwargs)
+        return self.ctx[which].encode(x, **kwargs)
+
+    # ---- the UNet forward ----------------------------------------------------------------------------
+    def _emb_silu(self, glayer_ptr, timesteps):
+        net = self.diffuser[glayer_ptr]
+        return net.time_embed.forward_silu(timestep_embedding(timesteps, net.model_channels))
+
+    @staticmethod
+    def _prep(x):
+        if not x.is_cuda:
+            raise RuntimeError("VD_v2_0.apply_model needs the latent on the GPU: this package has no CPU path")
+        return x.to(torch.float16).contiguous()
+
+    @torch.no_grad()
+    def apply_model(self, x_info, timesteps, c_info):
+        x_type, x = x_info["type"], x_info["x"]
+        c_type, c = c_info["type"], c_info["c"]
+        glayer_ptr = x_type if self.global_layer_ptr is None else self.global_layer_ptr
+        emb = self._emb_silu(glayer_ptr, timesteps)
+        spec = (self.diffuser[c_type].context_blocks, self._prep(c), 1.0, c_info.get("kv_cache"))
+        return run_unet(self.diffuser[x_type], [spec], self._prep(x), emb).to(x.dtype)
+
+    @torch.no_grad()
+    def apply_model_multicontext(self, x_info, timesteps, c_info_list, mixing_type="attention"):
+        """c_info_list: [{type, c, ratio}, ...]; 'attention' mixing = ratio-weighted sum of the context blocks."""
+        x_type, x = x_info["type"], x_info["x"]
+        assert mixing_type in ("attention", "layer")
+        emb = self._emb_silu(x_type, timesteps)  # reference takes time_embed from diffuser[x_type] here (vd.py:415-417)
+        specs = [(self.diffuser[ci["type"]].context_blocks, self._prep(ci["c"]), ci["ratio"], ci.get("kv_cache"))
+                 for ci in c_info_list]
+        return run_unet(self.diffuser[x_type], specs, self._prep(x), emb, mixing_type).to(x.dtype)
