@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""Headline benchmark: 512x512 images/sec at 50 DDIM steps (BASELINE.json metric), synthetic inputs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: a guided (CFG 7.5) 50-step DDIM loop over a batch of
+`--batch` (default 4) 64x64x4 latents with a [B,77,768] text context, followed by the KL-f8 decode to 512x512
+-- BASELINE.json configs[1] ("text-to-image 512x512, 50 DDIM steps, bs=4 fp16, 1xMI355X").  Context encoding
+(CLIP) is outside the timed region.  Inputs (latents, contexts, weights) are resident in HBM when
+timing starts.  With N > 1 every rank samples its own batch (batch-axis sharding, weak scaling) and the decoded
+images are all-gathered over RCCL inside the timed region.
+
+The JSON line also carries
+  roofline      -- for the kernel that dominates a UNet forward: algorithmic FLOPs of its launches / their measured
+                   duration (events on the launch stream), against the dense fp16 MFMA peak of MI355X
+  cpu_baseline  -- the CPU fp32 oracle (oracle/vd_oracle.py, kind "port") timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("VD_QUIET", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_FP16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md chip-level table
+HBM_PEAK_GBS = 8000.0
+UNET_GF_PER_SAMPLE = 803.3       # 64x64 latent, text ctx L=77
+VAE_DECODE_GF = 2514.5
+
+
+def build_model(device, seed=0):
+    """vd_four_flow_v1-0's image path: openai_unet_2d_v1 + the text context blocks (openai_unet_0d_v1_c) + kl-f8,
+    random-init weights of that architecture generated on the device (no checkpoints offline)."""
+    from lib.cfg_helper import CfgDict, model_cfg_bank
+    from lib.model_zoo import get_model
+    bank = model_cfg_bank()
+    vae = bank("autokl_v1")
+    vae.pop("pth", None)
+    cfg = CfgDict(type="vd_v2_0", args=CfgDict(
+        vae_cfg_list=[["image", vae]], ctx_cfg_list=[["image", "ctx-image-placeholder"], ["text", "ctx-text-placeholder"]],
+        diffuser_cfg_list=[["image", bank("openai_unet_2d_v1")], ["text", bank("openai_unet_0d_v1_c")]],
+        global_layer_ptr="image", latent_scale_factor={"image": 0.18215}, beta_linear_start=0.00085,
+        beta_linear_end=0.012, timesteps=1000, use_ema=False))
+    torch.manual_seed(seed)
+    with torch.device(device):
+        net = get_model()(cfg, verbose=False)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() >= 2:   # fan-in scaled normal incl. the zero-initialised convs (else the UNet outputs 0)
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device=device) / fan_in ** 0.5)
+            elif name.endswith("bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g, device=device))
+    net = net.half()
+    net.to(device)
+    return net
+
+
+def one_batch(net, sampler, batch, ctx, uctx, steps, seed, device):
+    torch.manual_seed(seed + 100)  # reference convention: torch.manual_seed(seed + 100), app.py:309
+    c_info = {"type": "text", "conditioning": ctx, "unconditional_conditioning": uctx,
+              "unconditional_guidance_scale": 7.5}
+    z, _ = sampler.sample(steps=steps, shape=[batch, 4, 64, 64], x_info={"type": "image"}, c_info=c_info, eta=0.,
+                          verbose=False)
+    return net.vae_decode(z, which="image")
+
+
+def roofline_leg(net, batch, ctx, uctx, device):
+    """One instrumented UNet forward at the benchmark shape (CFG batch 2B): per-launch events + algorithmic FLOPs."""
+    from vd_hip import ops
+    x = torch.randn(2 * batch, 4, 64, 64, device=device, dtype=torch.float16)
+    t = torch.full((2 * batch,), 501, device=device, dtype=torch.long)
+    c = torch.cat([uctx, ctx])
+    for _ in range(2):
+        net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+    torch.cuda.synchronize()
+    agg = {}
+    reps = 3
+    for _ in range(reps):
+        ops.profile_begin()
+        net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+        for name, fl, by, ms in ops.profile_end():
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
+    table = {n: dict(launches=a[0] // reps, gflop=a[1] / reps / 1e9, mbytes=a[2] / reps / 1e6, ms=a[3] / reps,
+                     avg_us=1e3 * a[3] / a[0]) for n, a in agg.items()}
+    dom = max(table, key=lambda n: table[n]["ms"])
+    d = table[dom]
+    achieved = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
+    roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_forward": d["launches"], "avg_launch_us": round(d["avg_us"], 1),
+            "algorithmic_gflop_per_launch": round(d["gflop"] / max(d["launches"], 1), 2),
+            "forward_ms_instrumented": round(sum(v["ms"] for v in table.values()), 3)}
+    return roof, table
+
+
+def cpu_baseline_leg(net, device):
+    """CPU fp32 oracle on a bounded sample: one CFG-batch-2 UNet forward (64x64 latent, L=77) and one 32x32-latent
+    VAE decode (scaled x4 to 64x64 by area); extrapolated to images/sec at 50 steps."""
+    from oracle import vd_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 4, 64, 64), generator=g)
+    c = torch.randn((2, 77, 768), generator=g) * 0.5
+    t = torch.tensor([501, 501])
+    plan = O.unet_plan()
+    with torch.no_grad():
+        t0 = time.time()
+        O.apply_model(sd, plan, x, t, c, c_type="text", global_ptr="image")
+        t_fwd = time.time() - t0
+        z = torch.randn((1, 4, 32, 32), generator=g)
+        t0 = time.time()
+        O.vae_decode(sd, "vae.image", z)
+        t_dec = (time.time() - t0) * 4.0
+    per_image = 50 * t_fwd + t_dec
+    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle fp32: 1 UNet forward (CFG batch 2, 64x64x4 latent, L=77) = %.2f s; 1 VAE decode 32x32 "
+                      "latent x4 area = %.2f s; extrapolated 50*forward + decode per image" % (t_fwd, t_dec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed batches (each = 50 DDIM steps + decode)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernel-table", default=None, help="write the per-kernel table of the roofline leg here")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus or not distributed, "launch with --nproc-per-node == --gpus"
+
+    from lib.model_zoo.ddim import DDIMSampler
+    net = build_model(device)
+    sampler = DDIMSampler(net)
+    B = args.batch
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    ctx = (torch.randn((B, 77, 768), generator=g, device=device) * 0.5).half()
+    uctx = (torch.randn((1, 77, 768), generator=g, device=device) * 0.5).half().repeat(B, 1, 1)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+    for i in range(args.warmup):
+        img = one_batch(net, sampler, B, ctx, uctx, args.ddim_steps, i, device)
+        if distributed:
+            gathered = [torch.empty_like(img) for _ in range(world)]
+            dist.all_gather(gathered, img)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = one_batch(net, sampler, B, ctx, uctx, args.ddim_steps, 10 + i, device)
+        if distributed:
+            if gathered is None:
+                gathered = [torch.empty_like(img) for _ in range(world)]
+            dist.all_gather(gathered, img)   # the one collective of the path: decoded images over RCCL/xGMI
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert img.shape == (B, 3, 512, 512) and bool(torch.isfinite(img).all())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    out = {
+        "metric": "512x512 images/sec (50-step DDIM)", "value": round(value, 4), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "text-to-image 512x512 (64x64x4 latent), %d DDIM steps, CFG 7.5, bs=%d per GPU, fp16, "
+                               "single text-context flow (vd_four_flow_v1-0 UNet 859.5M + text context blocks) + kl-f8 "
+                               "decode; CLIP context encoding outside the timed region" % (args.ddim_steps, B),
+                   "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": "batch-shard x%d" % world,
+                   "weights": "random-init (fan-in scaled normal), no checkpoints offline"},
+    }
+    if rank == 0:
+        alg_tf = B * (2 * args.ddim_steps * UNET_GF_PER_SAMPLE + VAE_DECODE_GF) / 1e3
+        out["algorithmic_tflop_per_step"] = round(alg_tf, 1)
+        out["whole_path_tflops_per_gpu"] = round(alg_tf / (ms_per_step / 1e3), 1)
+        out["whole_path_frac_of_mfma_peak"] = round(alg_tf / (ms_per_step / 1e3) / MFMA_FP16_PEAK_TFLOPS, 4)
+        if not args.no_roofline:
+            # per-DDIM-step device time of the UNet forward + update, HIP events over 20 warm steps (metric ii)
+            x = torch.randn(B, 4, 64, 64, device=device, dtype=torch.float16)
+            sampler.make_schedule(args.ddim_steps, verbose=False)
+            c_info = {"type": "text", "c": torch.cat([uctx, ctx]), "kv_cache": {}}
+            for _ in range(3):
+                sampler._step(x, {"type": "image"}, [c_info], 501, 25, True, 7.5, 1.0, True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                sampler._step(x, {"type": "image"}, [c_info], 501, 25, True, 7.5, 1.0, True)
+            e1.record()
+            torch.cuda.synchronize()
+            out["unet_forward_ms_per_ddim_step_bs%d" % B] = round(e0.elapsed_time(e1) / 20, 3)
+            roof, table = roofline_leg(net, B, ctx, uctx, device)
+            out["roofline"] = roof
+            if args.dump_kernel_table:
+                with open(args.dump_kernel_table, "w") as f:
+                    json.dump(table, f, indent=1, sort_keys=True)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(net, device)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,9 @@ typedef struct VdGemmDesc {
  *   HF CLIP linear layers reached from lib/model_zoo/clip.py:58-61,95-100 */
 int vd_gemm_f16(const VdGemmDesc* desc, hipStream_t stream);
 size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
+/* Dry run of the launch heuristic: tile_cfg 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; nsplit = split-K factor.
+ * Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
+int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
 
 /* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
  * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().

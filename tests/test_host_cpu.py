@@ -28,8 +28,8 @@ def test_capi_exports_every_declared_symbol():
     # argument validation works without a device
     from vd_hip.loader import VdGemmDesc
     d = VdGemmDesc()
-    d.M, d.N, d.K = 4, 4, 72
-    assert h.vd_gemm_f16(ctypes.byref(d), None) < 0 and b"multiple of 64" in h.vd_last_error()
+    d.M, d.N, d.K = 4, 4, 68
+    assert h.vd_gemm_f16(ctypes.byref(d), None) < 0 and b"multiple of 8" in h.vd_last_error()
     assert h.vd_groupnorm_workspace_bytes(8, 4096, 320, 32) > 0
 
 

@@ -42,7 +42,7 @@ def test_mfma_layout_probe(ops, dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 192, 128), (77, 768, 768), (4096, 64, 2560),
-                                   (33, 8, 64), (512, 1280, 1280), (130, 4, 320)])
+                                   (33, 8, 64), (512, 1280, 1280), (130, 4, 320), (100, 72, 16), (256, 128, 200)])
 def test_gemm_plain(ops, dev, M, N, K):
     a = rnd((M, K), dev, 1.0, 1)
     w = rnd((N, K), dev, 0.05, 2)
@@ -368,9 +368,9 @@ def test_clip_helpers(ops, dev):
 
 def test_error_reporting(ops, dev):
     from vd_hip import VdHipError
-    a = rnd((64, 72), dev)
-    w = rnd((64, 72), dev)
-    with pytest.raises(VdHipError, match="multiple of 64"):
+    a = rnd((64, 68), dev)
+    w = rnd((64, 68), dev)
+    with pytest.raises(VdHipError, match="multiple of 8"):
         ops.gemm(a, w)
     with pytest.raises(VdHipError, match="GPU"):
         ops.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(64).half(), torch.zeros(64).half())

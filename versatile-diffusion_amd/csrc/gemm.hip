@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const int iy = a_iy0[ps] + ky, ix = a_ix0[ps] + kx;
-            const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+            const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv) && (kglob + lslot * 8 < d.K);
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
                 const size_t pix = (size_t)a_pix[ps] + (size_t)((iy >> d.ups) * d.Win + (ix >> d.ups));
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         for (int ps = 0; ps < B_PASSES; ++ps) {
             const int n = n0 + lrow + 32 * ps;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < d.N) v = *reinterpret_cast<const uint4*>(wp + (size_t)n * d.ldw + kglob + lslot * 8);
+            if (n < d.N && kglob + lslot * 8 < d.K)
+                v = *reinterpret_cast<const uint4*>(wp + (size_t)n * d.ldw + kglob + lslot * 8);
             rb[ps] = v;
         }
     };
@@ -438,13 +439,18 @@ extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
     return batch * 16 * (size_t)d->M * (size_t)d->N * sizeof(float);
 }
 
-extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
+namespace {
+enum TileCfg { T128x128 = 0, T128x64 = 1, T64x64 = 2 };
+
+// validate + normalise the descriptor and pick tile shape / split factor
+int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) {
     VD_REQUIRE(dp != nullptr, "vd_gemm_f16: null descriptor");
-    GemmArgs a;
     a.d = *dp;
     VdGemmDesc& d = a.d;
     VD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "vd_gemm_f16: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
-    VD_REQUIRE(d.K % BK == 0, "vd_gemm_f16: K=%d must be a multiple of %d (pad small-K operands with vd_im2col_small)", d.K, BK);
+    VD_REQUIRE(d.K % 8 == 0, "vd_gemm_f16: K=%d must be a multiple of 8 (pad small-K operands with vd_im2col_small)", d.K);
+    if (d.K % BK != 0)  // ragged K tail is zero-filled by the loader; only plain single-source matrices
+        VD_REQUIRE(d.ksize <= 1 && d.a1 == nullptr, "vd_gemm_f16: conv/concat operands need K %% %d == 0 (K=%d)", BK, d.K);
     if (d.ksize <= 0) d.ksize = 1;
     if (d.stride <= 0) d.stride = 1;
     if (d.c0 <= 0) d.c0 = d.K / (d.ksize * d.ksize);
@@ -471,10 +477,10 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     VD_REQUIRE(d.a0 && d.w && d.out, "vd_gemm_f16: null operand");
     if (d.act == VD_ACT_GEGLU) VD_REQUIRE(d.N % 128 == 0, "vd_gemm_f16: GEGLU needs N %% 128 == 0");
 
-    a.kt_total = d.K / BK;
+    a.kt_total = (d.K + BK - 1) / BK;
 
     // ---- tile / split heuristic: fill >= ~1 wave of the 256 CUs (2 blocks per CU resident)
-    enum { T128x128, T128x64, T64x64 } cfg;
+    TileCfg cfg;
     auto tiles = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
     const int zb = d.batch;
     if (d.act == VD_ACT_GEGLU) cfg = T128x128;
@@ -506,8 +512,30 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     }
     a.kt_per_split = (a.kt_total + nsplit - 1) / nsplit;
     nsplit = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
+    cfg_out = (int)cfg;
+    nsplit_out = nsplit;
+    return VD_OK;
+}
+}  // namespace
 
-    int rc;
+extern "C" int vd_gemm_plan(const VdGemmDesc* dp, int* tile_cfg, int* nsplit) {
+    GemmArgs a;
+    int c = 0, n = 1;
+    const int rc = plan_gemm(dp, a, c, n);
+    if (rc != VD_OK) return rc;
+    if (tile_cfg) *tile_cfg = c;
+    if (nsplit) *nsplit = n;
+    return VD_OK;
+}
+
+extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
+    GemmArgs a;
+    int cfg = 0, nsplit = 1;
+    int rc = plan_gemm(dp, a, cfg, nsplit);
+    if (rc != VD_OK) return rc;
+    const VdGemmDesc& d = a.d;
+    const int zb = d.batch;
+
     switch (cfg) {
         case T128x128: rc = launch_cfg<128, 128, 64, 64>(a, nsplit, stream); break;
         case T128x64: rc = launch_cfg<128, 64, 64, 32>(a, nsplit, stream); break;

@@ -28,7 +28,7 @@ class String_Reg_Buffer(nn.Module):
 
     def __init__(self, output_string):
         super().__init__()
-        self.register_buffer("output_string", torch.ByteTensor(list(bytes(output_string, "utf8"))))
+        self.register_buffer("output_string", torch.tensor(list(bytes(output_string, "utf8")), dtype=torch.uint8))
 
     @torch.no_grad()
     def forward(self, *args, **kwargs):

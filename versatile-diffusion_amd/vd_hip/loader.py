@@ -32,6 +32,7 @@ _P, _I, _F, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int
 PROTOTYPES = {
     "vd_gemm_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P]),
     "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
+    "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

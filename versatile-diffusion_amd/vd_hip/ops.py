@@ -16,6 +16,42 @@ ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3
 
 _ws_cache = {}
 
+# ---- optional per-launch instrumentation (bench.py roofline leg; off in the product path) -------------
+_prof = None
+GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64>", "gemm_f16_kernel<128,64,64,32>", "gemm_f16_kernel<64,64,32,32>")
+
+
+def profile_begin():
+    """Start recording (kernel name, algorithmic flops, algorithmic bytes, start/stop events) per launch."""
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """Stop recording; returns [(name, flops, bytes, ms)] after synchronising."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(n, f, b, e0.elapsed_time(e1)) for n, f, b, e0, e1 in rec]
+
+
+class _Timed(object):
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
+        return False
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -107,7 +143,14 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         d.ws = workspace(nb, a0.device, "gemm").data_ptr()
     else:
         d.ws = None
-    _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
+    name = "gemm"
+    if _prof is not None:
+        cfg, ns = ctypes.c_int(0), ctypes.c_int(1)
+        _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)))
+        name = GEMM_KERNEL_NAMES[cfg.value]
+    nb = max(batch, 1)
+    with _Timed(name, 2.0 * nb * M * N * K, 2.0 * nb * (M * K + N * K + M * n_out)):
+        _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
     return out
 
 
@@ -145,8 +188,9 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
         out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
     nb = lib().vd_groupnorm_workspace_bytes(B, HW, C, groups)
     ws = workspace(nb, x.device, "gn")
-    _check(lib().vd_groupnorm_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), B, HW,
-                                       groups, float(eps), 1 if silu else 0, _stream()))
+    with _Timed("groupnorm(3 kernels)", 0.0, 2.0 * B * HW * C * 3):
+        _check(lib().vd_groupnorm_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), B, HW,
+                                           groups, float(eps), 1 if silu else 0, _stream()))
     return out
 
 
@@ -156,7 +200,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     rows = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
-    _check(lib().vd_layernorm_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, C, float(eps), _stream()))
+    with _Timed("layernorm_kernel", 0.0, 2.0 * rows * C * 2):
+        _check(lib().vd_layernorm_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, C, float(eps), _stream()))
     return out
 
 
@@ -174,9 +219,10 @@ def attention(q, k, v, heads, *, scale=None, causal=False, out=None):
         out = torch.empty((B, Nq, C), dtype=torch.float16, device=q.device)
     if scale is None:
         scale = D ** -0.5
-    _check(lib().vd_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, q.stride(1), k.stride(1),
-                                  v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                  float(scale), 1 if causal else 0, _stream()))
+    with _Timed("attn_fwd_kernel<%d>" % D, 4.0 * B * Nq * Nk * C, 2.0 * B * C * (2 * Nq + 2 * Nk)):
+        _check(lib().vd_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, q.stride(1), k.stride(1),
+                                      v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                      float(scale), 1 if causal else 0, _stream()))
     return out
 
 
