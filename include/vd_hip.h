@@ -32,6 +32,7 @@ typedef struct ihipStream_t* hipStream_t;
 #endif
 
 #define VD_HIP_ABI_VERSION 1
+#define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
 #define VD_EPI_BIAS 1         /* + bias[n]                                                    */
@@ -41,7 +42,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
 
 #define VD_ACT_NONE 0
-#define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 128 rows as [64 val | 64 gate] */
+#define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
 #define VD_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x)  (HF CLIP)                                 */
 #define VD_ACT_SILU 3
 

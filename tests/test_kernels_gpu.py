@@ -63,21 +63,37 @@ def test_gemm_asymmetric_identity(ops, dev):
 
 @pytest.mark.parametrize("act", ["none", "quick_gelu", "silu"])
 def test_gemm_epilogue(ops, dev, act):
-    M, N, K, rpb = 512, 320, 192, 128
+    M, N, K = 512, 320, 192
     a = rnd((M, K), dev, 1.0, 3)
     w = rnd((N, K), dev, 0.05, 4)
     bias = rnd((N,), dev, 0.5, 5)
-    rowvec = rnd((M // rpb, N), dev, 0.5, 6)
     res = rnd((M, N), dev, 1.0, 7)
-    v = a.float() @ w.float().t() + bias.float() + rowvec.float().repeat_interleave(rpb, 0)
+    v = a.float() @ w.float().t() + bias.float()
     if act == "quick_gelu":
         v = v * torch.sigmoid(1.702 * v)
     elif act == "silu":
         v = F.silu(v)
     ref = v * 0.7 + res.float()
     code = {"none": ops.ACT_NONE, "quick_gelu": ops.ACT_QUICK_GELU, "silu": ops.ACT_SILU}[act]
-    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_batch=rpb, res=res, act=code, alpha=0.7)
+    out = ops.gemm(a, w, bias=bias, res=res, act=code, alpha=0.7)
     assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,rpb", [(512, 320, 128), (384, 1280, 64), (200, 72, 50)])
+def test_gemm_rowvec_residual(ops, dev, M, N, rpb):
+    """ResBlock epilogues: + bias + emb[batch] broadcast over the rows of a sample, + residual."""
+    K = 192
+    a = rnd((M, K), dev, 1.0, 3)
+    w = rnd((N, K), dev, 0.05, 4)
+    bias = rnd((N,), dev, 0.5, 5)
+    rowvec = rnd((M // rpb, N), dev, 0.5, 6)
+    res = rnd((M, N), dev, 1.0, 7)
+    ref = a.float() @ w.float().t() + bias.float() + rowvec.float().repeat_interleave(rpb, 0) + res.float()
+    out = ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_batch=rpb, res=res)
+    assert rel_l2(out, ref) < 2e-3
+    from vd_hip import VdHipError
+    with pytest.raises(VdHipError, match="rowvec"):
+        ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_batch=rpb, alpha=0.5)
 
 
 def test_gemm_geglu(ops, dev):
@@ -95,7 +111,7 @@ def test_gemm_geglu(ops, dev):
     assert rel_l2(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("split", [2, 5, 16])
+@pytest.mark.parametrize("split", [2, 5, 16, 32])
 def test_gemm_split_k(ops, dev, split):
     M, N, K = 192, 320, 64 * 40
     a = rnd((M, K), dev, 1.0, 11)

@@ -1,0 +1,32 @@
+"""Per-shape kernel table of one UNet forward at the benchmark shape (dev tool; run on the GPU box)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+os.environ.setdefault("VD_QUIET", "1")
+import torch
+import bench
+from vd_hip import ops
+
+dev = torch.device("cuda:0")
+net = bench.build_model(dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+x = torch.randn(2 * B, 4, 64, 64, device=dev, dtype=torch.float16)
+t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+c = torch.randn(2 * B, 77, 768, device=dev, dtype=torch.float16) * 0.5
+for _ in range(2):
+    net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+ops.PROFILE_SHAPES = True
+agg = {}
+reps = 5
+for _ in range(reps):
+    ops.profile_begin()
+    net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+    for name, fl, by, ms in ops.profile_end():
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += fl; a[2] += ms
+rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+tot = sum(a[2] for _, a in rows) / reps
+print("total %.3f ms" % tot)
+for name, a in rows:
+    n = a[0] // reps
+    print("%7.3f ms %5.1f%% n=%3d avg=%7.1f us %7.1f TF/s  %s" % (a[2] / reps, 100 * a[2] / reps / tot, n, 1e3 * a[2] / a[0], a[1] / a[2] / 1e9 if a[2] else 0, name))

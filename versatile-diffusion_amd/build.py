@@ -16,6 +16,11 @@ OUT = os.path.join(HERE, "libvd_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the
+# v_accvgpr_read/write shuffle and lowers the register footprint (2 -> 3 waves/SIMD for head dim 40)
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # GEMM: without it the accumulators bounce AGPR<->VGPR (64 reads + 64 writes) every K tile
+               "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():
@@ -42,7 +47,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -22,6 +22,7 @@ namespace {
 constexpr int KV = 64;    // keys per tile
 constexpr int QB = 128;   // queries per block (4 waves x 32)
 constexpr int VROW = KV + 4;  // V^T row stride in halfs: 136 bytes -> conflict-free ds_read_b64
+constexpr float RESCALE_THR = 6.0f;  // log2 units: P values stay <= 64 between rescales
 
 struct AttnArgs {
     const f16* q;
@@ -164,37 +165,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
         // ---- online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
         const int key0 = t * KV;
-        float mx = -INFINITY;
+        // masking is needed only on the ragged last tile / on tiles that cross the causal diagonal (wave-uniform)
+        const bool need_mask = (key0 + KV > p.Nk) || (p.causal && (key0 + KV - 1 > qb * QB + wave * 32));
+        if (need_mask) {
+#pragma unroll
+            for (int kt = 0; kt < KV / 32; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.Nk || (p.causal && key > qrow)) st[kt][r] = -INFINITY;
+                }
+        }
+        float mx = st[0][0];
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float s = st[kt][r] * p.scale_log2;
-                if (key >= p.Nk || (p.causal && key > qrow)) s = -INFINITY;
-                st[kt][r] = s;
-                mx = fmaxf(mx, s);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        const float ms = mx * p.scale_log2;  // running max is tracked in scaled (log2) units
+        // Deferred rescale: the accumulators are only rescaled when some row's max grew by more than RESCALE_THR
+        // (then every lane updates exactly); otherwise P = exp2(s - m_old) <= 2^RESCALE_THR, harmless in fp16/fp32.
+        if (__any(ms > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, ms);
+            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
         float psum = 0.f;
         f16x8 pb[KV / 32][2];
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pe = exp2f(st[kt][r] - m_use);
+                const float pe = __builtin_amdgcn_exp2f(fmaf(st[kt][r], p.scale_log2, neg_m));
                 psum += pe;
                 pb[kt][r >> 3][r & 7] = (f16)pe;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3)
 #pragma unroll

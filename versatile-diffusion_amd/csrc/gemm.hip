@@ -31,7 +31,19 @@ constexpr int ROW_BYTES = BK * 2;
 struct GemmArgs {
     VdGemmDesc d;
     int tiles_m, tiles_n, kt_total, kt_per_split;
+    unsigned a0_bytes, a1_bytes, w_bytes;  // per-batch operand extents for the buffer descriptors (< 2^31)
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 // swizzled byte offset of (row r, 16-byte slot s) inside a [rows][64] f16 LDS tile
 __device__ __forceinline__ int lds_off(int r, int s) { return r * ROW_BYTES + ((s ^ ((r >> 1) & 7)) << 4); }
@@ -44,95 +56,6 @@ struct EpiCtx {
     int N, ldc, ldr, rows_per_batch, flags, act;
     float alpha;
 };
-
-// Apply the fused epilogue to 8 consecutive output columns of one row and store them.
-// Order: v = acc (+bias) (+rowvec[batch]) -> act -> *alpha -> (+residual).
-__device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, float* v, const float* g) {
-    const bool full = (col + 8 <= e.N) && ((e.N & 7) == 0);
-    float b[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = 0.f;
-    if (e.flags & VD_EPI_BIAS) {
-        if (e.flags & VD_EPI_BIAS_ALONG_M) {
-            const float bv = (float)e.bias[row];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) b[i] = bv;
-        } else if (full) {
-            U4H8 t;
-            t.u = *reinterpret_cast<const uint4*>(e.bias + col);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) b[i] = (float)t.e[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (col + i < e.N) b[i] = (float)e.bias[col + i];
-        }
-    }
-    if (e.flags & VD_EPI_ROWVEC) {
-        const f16* rv = e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col;
-        if (full) {
-            U4H8 t;
-            t.u = *reinterpret_cast<const uint4*>(rv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) b[i] += (float)t.e[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (col + i < e.N) b[i] += (float)rv[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += b[i];
-    if (e.act == VD_ACT_GEGLU) {
-        // g = gate pre-activations (bias for the gate half is folded by the caller)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] * vd_gelu_erf(g[i]);
-    } else if (e.act == VD_ACT_QUICK_GELU) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = vd_quick_gelu(v[i]);
-    } else if (e.act == VD_ACT_SILU) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = vd_silu(v[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
-    if (e.flags & VD_EPI_RESIDUAL) {
-        const f16* rp = e.res + (size_t)row * e.ldr + col;
-        if (full && ((e.ldr & 7) == 0)) {
-            U4H8 t;
-            t.u = *reinterpret_cast<const uint4*>(rp);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += (float)t.e[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (col + i < e.N) v[i] += (float)rp[i];
-        }
-    }
-    if (e.flags & VD_EPI_OUT_F32) {
-        float* op = reinterpret_cast<float*>(e.out) + (size_t)row * e.ldc + col;
-        if (full && ((e.ldc & 3) == 0)) {
-            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (col + i < e.N) op[i] = v[i];
-        }
-    } else {
-        f16* op = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
-        if (full && ((e.ldc & 7) == 0)) {
-            U4H8 t;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t.e[i] = (f16)v[i];
-            *reinterpret_cast<uint4*>(op) = t.u;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (col + i < e.N) op[i] = (f16)v[i];
-        }
-    }
-}
 
 __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
     EpiCtx e;
@@ -153,6 +76,74 @@ __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
     return e;
 }
 
+__device__ __forceinline__ float apply_act(int act, float v) {
+    if (act == VD_ACT_QUICK_GELU) return vd_quick_gelu(v);
+    if (act == VD_ACT_SILU) return vd_silu(v);
+    return v;
+}
+
+// Second half of the epilogue for 8 consecutive output columns of one row (values already carry
+// bias / activation / alpha): + rowvec[batch] (+ residual) and the 16-byte store.
+__device__ __forceinline__ void epi_finish8(const EpiCtx& e, int row, int col, float* v) {
+    const bool full = (col + 8 <= e.N) && ((e.N & 7) == 0);
+    if (e.flags & VD_EPI_ROWVEC) {
+        const f16* rv = e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col;
+        if (full) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)t.e[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (col + i < e.N) v[i] += (float)rv[i];
+        }
+    }
+    if (e.flags & VD_EPI_RESIDUAL) {
+        const f16* rp = e.res + (size_t)row * e.ldr + col;
+        if (full && ((e.ldr & 7) == 0)) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(rp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)t.e[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (col + i < e.N) v[i] += (float)rp[i];
+        }
+    }
+    f16* op = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+    if (full && ((e.ldc & 7) == 0)) {
+        U4H8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t.e[i] = (f16)v[i];
+        *reinterpret_cast<uint4*>(op) = t.u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) op[i] = (f16)v[i];
+    }
+}
+
+// Full fp32 epilogue for 8 columns (split-K reduce kernel): bias, rowvec, act, alpha, residual, store.
+__device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, float* v) {
+    if (e.flags & VD_EPI_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) v[i] += (float)((e.flags & VD_EPI_BIAS_ALONG_M) ? e.bias[row] : e.bias[col + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = apply_act(e.act, v[i]) * e.alpha;
+    if (e.flags & VD_EPI_OUT_F32) {
+        float* op = reinterpret_cast<float*>(e.out) + (size_t)row * e.ldc + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) op[i] = v[i];
+        return;
+    }
+    epi_finish8(e, row, col, v);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int WAVES_N = BN / WN;
@@ -161,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int CS_LD = BN + 4;  // fp32 epilogue tile leading dimension
+    constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -185,11 +176,15 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     const int split = blockIdx.y;
     const int z = blockIdx.z;
 
-    const f16* a0 = reinterpret_cast<const f16*>(d.a0) + (size_t)z * d.stride_a;
-    const f16* a1 = reinterpret_cast<const f16*>(d.a1) + (size_t)z * d.stride_a;
-    const f16* wp = reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w;
+    // ---- operands are read through buffer descriptors: one SGPR base + per-lane 32-bit byte offset + a scalar
+    // K offset per tile.  Out-of-image taps, rows >= M / N and the ragged K tail simply use an out-of-range
+    // offset and the hardware returns zeros: no branches and (within a conv tap) no VALU work per K tile.
+    const __amdgpu_buffer_rsrc_t rs_a0 = make_rsrc(reinterpret_cast<const f16*>(d.a0) + (size_t)z * d.stride_a, p.a0_bytes);
+    const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(d.a1 ? reinterpret_cast<const f16*>(d.a1) + (size_t)z * d.stride_a : d.a0,
+                                                   d.a1 ? p.a1_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
 
-    // ---- per-thread gather coordinates: 8 threads per 128-byte row, 32 rows per pass
+    // per-thread gather coordinates: 8 threads per 128-byte row, 32 rows per pass
     const int lrow = tid >> 3, lslot = tid & 7;
     int a_iy0[A_PASSES], a_ix0[A_PASSES], a_pix[A_PASSES];
     const int HWo = d.Hout * d.Wout;
@@ -211,55 +206,66 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
             a_pix[ps] = 0;
         }
     }
+    unsigned voff_b[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int n = n0 + lrow + 32 * ps;
+        voff_b[ps] = (n < d.N) ? (unsigned)((n * d.ldw + lslot * 8) * 2) : OOB_OFFSET;
+    }
 
     const int ctot = d.c0 + d.c1;
-    int kt = split * p.kt_per_split;
-    int kt_end = kt + p.kt_per_split;
+    const int kt0 = split * p.kt_per_split;
+    int kt_end = kt0 + p.kt_per_split;
     if (kt_end > p.kt_total) kt_end = p.kt_total;
+    const int nk = kt_end - kt0;
+    const bool ragged = (d.K % BK) != 0;
 
-    uint4 ra[A_PASSES], rb[B_PASSES];
-
-    auto load_tile = [&](int t) {
+    // gather state of the current (tap, source) segment: per-pass byte offset of the pixel row, or OOB
+    unsigned voff_a[A_PASSES];
+    int cur_seg = -1;
+    auto load_tile = [&](int t, uint4* ra, uint4* rb) {
         const int kglob = t * BK;
         const int tap = kglob / ctot;
         int cc = kglob - tap * ctot;
-        const int ky = tap / d.ksize, kx = tap - ky * d.ksize;
-        const f16* src = a0;
-        int ld = d.lda0;
-        if (cc >= d.c0) {
-            src = a1;
-            ld = d.lda1;
-            cc -= d.c0;
+        const bool second = cc >= d.c0;
+        if (second) cc -= d.c0;
+        const int seg = tap * 2 + (second ? 1 : 0);
+        if (seg != cur_seg) {  // wave-uniform: new tap or switch to the concatenated source
+            cur_seg = seg;
+            const int ky = tap / d.ksize, kx = tap - ky * d.ksize;
+            const int ld = second ? d.lda1 : d.lda0;
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int iy = a_iy0[ps] + ky, ix = a_ix0[ps] + kx;
+                const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+                const int pix = a_pix[ps] + (iy >> d.ups) * d.Win + (ix >> d.ups);
+                voff_a[ps] = ok ? (unsigned)((pix * ld + lslot * 8) * 2) : OOB_OFFSET;
+            }
         }
+        const unsigned soff_a = (unsigned)cc * 2u, soff_b = (unsigned)kglob * 2u;
+        const bool kbad = ragged && (kglob + lslot * 8 >= d.K);
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
-            const int iy = a_iy0[ps] + ky, ix = a_ix0[ps] + kx;
-            const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv) && (kglob + lslot * 8 < d.K);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const size_t pix = (size_t)a_pix[ps] + (size_t)((iy >> d.ups) * d.Win + (ix >> d.ups));
-                v = *reinterpret_cast<const uint4*>(src + pix * ld + cc + lslot * 8);
-            }
-            ra[ps] = v;
+            const unsigned vo = kbad ? OOB_OFFSET : voff_a[ps];
+            ra[ps] = second ? buf_load16(rs_a1, vo, soff_a) : buf_load16(rs_a0, vo, soff_a);
         }
 #pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps) {
-            const int n = n0 + lrow + 32 * ps;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < d.N && kglob + lslot * 8 < d.K)
-                v = *reinterpret_cast<const uint4*>(wp + (size_t)n * d.ldw + kglob + lslot * 8);
-            rb[ps] = v;
-        }
+        for (int ps = 0; ps < B_PASSES; ++ps) rb[ps] = buf_load16(rs_w, kbad ? OOB_OFFSET : voff_b[ps], soff_b);
     };
-    auto store_tile = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES;
+    // LDS addressing: (row >> 1) & 7 is the same for every 32-row pass / fragment of a lane, so each lane needs one
+    // store offset and one read offset per k-step; passes and fragments are immediate offsets (32 rows = 4096 B).
+    const int st_off = lds_off(lrow, lslot);
+    auto store_tile = [&](int buf, const uint4* ra, const uint4* rb) {
+        char* sa = smem + buf * STAGE_BYTES + st_off;
         char* sb = sa + BM * ROW_BYTES;
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uint4*>(sa + lds_off(lrow + 32 * ps, lslot)) = ra[ps];
+        for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uint4*>(sa + ps * 32 * ROW_BYTES) = ra[ps];
 #pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps) *reinterpret_cast<uint4*>(sb + lds_off(lrow + 32 * ps, lslot)) = rb[ps];
+        for (int ps = 0; ps < B_PASSES; ++ps) *reinterpret_cast<uint4*>(sb + ps * 32 * ROW_BYTES) = rb[ps];
     };
 
+    // acc[i][j] holds the TRANSPOSED 32x32 sub-tile (MFMA A operand = W rows, B operand = activation rows):
+    // lane owns output row m = l31 and, per register group g = r>>2, four consecutive columns n = 8g + 4hi + (r&3).
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -268,120 +274,174 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt < kt_end) {
-        load_tile(kt);
-        store_tile(0);
+    int rd_a[BK / 16], rd_b[BK / 16];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+        rd_a[ks] = lds_off(wm * WM + l31, ks * 2 + hi);
+        rd_b[ks] = BM * ROW_BYTES + lds_off(wn * WN + l31, ks * 2 + hi);
     }
-    __syncthreads();
-
-    int buf = 0;
-    for (; kt < kt_end; ++kt) {
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);  // global loads stay in flight under the MFMAs below
-
-        const char* sa = smem + buf * STAGE_BYTES;
-        const char* sb = sa + BM * ROW_BYTES;
+    auto compute_tile = [&](int buf) {
+        const char* st = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 U4H8 t;
-                t.u = *reinterpret_cast<const uint4*>(sa + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
+                t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * ROW_BYTES);
                 af[i] = t.h;
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 U4H8 t;
-                t.u = *reinterpret_cast<const uint4*>(sb + lds_off(wn * WN + j * 32 + l31, ks * 2 + hi));
+                t.u = *reinterpret_cast<const uint4*>(st + rd_b[ks] + j * 32 * ROW_BYTES);
                 bf[j] = t.h;
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+
+    // ---- main loop: two register sets -> global loads run two K tiles ahead of the MFMAs, LDS double buffer,
+    // one barrier per K tile.
+    uint4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
+    if (nk > 0) {
+        load_tile(kt0, ra0, rb0);
+        if (nk > 1) load_tile(kt0 + 1, ra1, rb1);
+        store_tile(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int i = 0; i < nk; i += 2) {
+        if (i + 2 < nk) load_tile(kt0 + i + 2, ra0, rb0);
+        compute_tile(0);
+        if (i + 1 < nk) {
+            store_tile(1, ra1, rb1);
+            __syncthreads();
+            if (i + 3 < nk) load_tile(kt0 + i + 3, ra1, rb1);
+            compute_tile(1);
+            if (i + 2 < nk) store_tile(0, ra0, rb0);
+        }
         __syncthreads();
-        buf ^= 1;
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced 16-byte row segments
-    float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int col = wn * WN + j * 32 + l31;
-                cs[row * CS_LD + col] = acc[i][j][r];
-            }
-    __syncthreads();
+    const EpiCtx e = make_epi(d, z);
 
-    if (gridDim.y > 1) {
-        // split-K: raw fp32 partial slab [split][M][N]; the reduce kernel applies the epilogue
-        float* ws = d.ws + ((size_t)z * gridDim.y + split) * (size_t)d.M * d.N;
-        constexpr int CH = BN / 4;
-        for (int c = tid; c < BM * CH; c += 256) {
-            const int r = c / CH, cc = (c - r * CH) * 4;
-            const int row = m0 + r, col = n0 + cc;
-            if (row < d.M && col < d.N) {
-                const float* s = cs + r * CS_LD + cc;
-                float* o = ws + (size_t)row * d.N + col;
-                if (col + 4 <= d.N && (d.N & 3) == 0) {
-                    *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
-                } else {
-                    for (int i = 0; i < 4; ++i)
-                        if (col + i < d.N) o[i] = s[i];
+    // ---- split-K / fp32 output: straight from registers (4 consecutive floats per lane and group)
+    if (gridDim.y > 1 || (d.flags & VD_EPI_OUT_F32)) {
+        const bool partial = gridDim.y > 1;
+        float* base = partial ? d.ws + ((size_t)z * gridDim.y + split) * (size_t)d.M * d.N
+                              : reinterpret_cast<float*>(e.out);
+        const int ld = partial ? d.N : e.ldc;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + wm * WM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * WN + j * 32 + 8 * g + 4 * hi;
+                    if (row < d.M && col < d.N) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                        if (!partial) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float t = v[q];
+                                if ((e.flags & VD_EPI_BIAS) && col + q < d.N)
+                                    t += (float)((e.flags & VD_EPI_BIAS_ALONG_M) ? e.bias[row] : e.bias[col + q]);
+                                v[q] = apply_act(e.act, t) * e.alpha;
+                            }
+                        }
+                        float* o = base + (size_t)row * ld + col;
+                        if (col + 4 <= d.N && (ld & 3) == 0) {
+                            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < d.N) o[q] = v[q];
+                        }
+                    }
                 }
-            }
         }
         return;
     }
 
-    const EpiCtx e = make_epi(d, z);
-    if (d.act == VD_ACT_GEGLU) {
-        // weight rows are packed per 128-row group as [64 value rows | 64 gate rows]
-        constexpr int HALF = BN / 2;
-        constexpr int CH = HALF / 8;
-        for (int c = tid; c < BM * CH; c += 256) {
-            const int r = c / CH, cc = (c - r * CH) * 8;
-            const int row = m0 + r, col = tn * HALF + cc;
-            if (row < d.M && col < e.N) {
-                float v[8], g[8];
+    // ---- fused epilogue, part 1 (registers): + bias -> act / GEGLU -> * alpha -> fp16 into an LDS tile [BM][OUT_N]
+    f16* cs = reinterpret_cast<f16*>(smem);
+    const bool geglu = (d.act == VD_ACT_GEGLU);
+    const int out_bn = geglu ? BN / 2 : BN;          // output columns of this block tile
+    const int out_n0 = geglu ? tn * (BN / 2) : n0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    v[i] = cs[r * CS_LD + cc + i];
-                    g[i] = cs[r * CS_LD + HALF + cc + i];
-                }
-                if (d.flags & VD_EPI_BIAS) {
-                    // packed bias layout mirrors the packed weight rows
-                    const f16* bp = reinterpret_cast<const f16*>(d.bias) + n0;
+    for (int i = 0; i < MI; ++i) {
+        const int lrow_c = wm * WM + i * 32 + l31;
+        const int row = m0 + lrow_c;
+        float bm = 0.f;
+        if ((e.flags & VD_EPI_BIAS) && (e.flags & VD_EPI_BIAS_ALONG_M) && row < d.M) bm = (float)e.bias[row];
+        if (geglu) {
+            if constexpr (NI == 2) {
+                // weight rows are packed per 64-row group as [32 value rows | 32 gate rows]: j = 0 value, j = 1 gate
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        v[i] += (float)bp[cc + i];
-                        g[i] += (float)bp[HALF + cc + i];
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = wn * (WN / 2) + 8 * g + 4 * hi;     // column inside the block's output tile
+                    const int pn = n0 + wn * WN + 8 * g + 4 * hi;      // packed weight row of the value element
+                    U2H4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[i][0][g * 4 + q], gt = acc[i][1][g * 4 + q];
+                        if (e.flags & VD_EPI_BIAS) {
+                            v += (float)e.bias[pn + q];
+                            gt += (float)e.bias[pn + 32 + q];
+                        }
+                        o.e[q] = (f16)(v * vd_gelu_erf(gt) * e.alpha);
                     }
+                    *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
                 }
-                EpiCtx e2 = e;
-                e2.flags &= ~VD_EPI_BIAS;
-                epi_store8(e2, row, col, v, g);
             }
-        }
-    } else {
-        constexpr int CH = BN / 8;
-        for (int c = tid; c < BM * CH; c += 256) {
-            const int r = c / CH, cc = (c - r * CH) * 8;
-            const int row = m0 + r, col = n0 + cc;
-            if (row < d.M && col < d.N) {
-                float v[8];
+        } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = cs[r * CS_LD + cc + i];
-                epi_store8(e, row, col, v, nullptr);
-            }
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = wn * WN + j * 32 + 8 * g + 4 * hi;
+                    const int col = n0 + lc;
+                    float bq[4] = {bm, bm, bm, bm};
+                    if ((e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M)) {
+                        if (col + 4 <= d.N && (d.N & 3) == 0) {
+                            U2H4 t;
+                            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < d.N) bq[q] = (float)e.bias[col + q];
+                        }
+                    }
+                    U2H4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o.e[q] = (f16)(apply_act(e.act, acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                    *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
+    const int ch_per_row = out_bn / 8;
+    for (int c = tid; c < BM * ch_per_row; c += 256) {
+        const int r = c / ch_per_row, cc = (c - r * ch_per_row) * 8;
+        const int row = m0 + r, col = out_n0 + cc;
+        if (row < d.M && col < e.N) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)t.e[i];
+            epi_finish8(e, row, col, v);
         }
     }
 }
@@ -411,14 +471,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
                     if (col + i < d.N) v[i] += w[i];
             }
         }
-        epi_store8(e, row, col, v, nullptr);
+        epi_store8(e, row, col, v);
     }
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int EPI_BYTES = BM * (BN + 4) * 4;
+    constexpr int EPI_BYTES = BM * (BN + 8) * 2;
     constexpr int LDS = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
@@ -434,9 +494,9 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
 }  // namespace
 
 extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
-    // upper bound for any split factor the heuristic may choose (<= 16)
+    // upper bound for any split factor the heuristic may choose
     const size_t batch = d->batch > 0 ? d->batch : 1;
-    return batch * 16 * (size_t)d->M * (size_t)d->N * sizeof(float);
+    return batch * VD_MAX_SPLIT_K * (size_t)d->M * (size_t)d->N * sizeof(float);
 }
 
 namespace {
@@ -476,17 +536,33 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     if (d.flags & VD_EPI_RESIDUAL) VD_REQUIRE(d.res != nullptr, "vd_gemm_f16: residual flag without pointer");
     VD_REQUIRE(d.a0 && d.w && d.out, "vd_gemm_f16: null operand");
     if (d.act == VD_ACT_GEGLU) VD_REQUIRE(d.N % 128 == 0, "vd_gemm_f16: GEGLU needs N %% 128 == 0");
+    if (d.flags & VD_EPI_ROWVEC)
+        VD_REQUIRE(d.act == VD_ACT_NONE && d.alpha == 1.0f, "vd_gemm_f16: rowvec epilogue requires act=none, alpha=1");
+    if (d.flags & VD_EPI_OUT_F32)
+        VD_REQUIRE(!(d.flags & (VD_EPI_ROWVEC | VD_EPI_RESIDUAL)) && d.act != VD_ACT_GEGLU, "vd_gemm_f16: fp32 output supports bias/act/alpha only");
 
     a.kt_total = (d.K + BK - 1) / BK;
+    {
+        const size_t in_rows = (size_t)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win;
+        const size_t a0b = in_rows * (size_t)d.lda0 * 2, a1b = d.a1 ? in_rows * (size_t)d.lda1 * 2 : 0;
+        const size_t wb = (size_t)d.N * d.ldw * 2;
+        VD_REQUIRE(a0b < (1ull << 31) && a1b < (1ull << 31) && wb < (1ull << 31),
+                   "vd_gemm_f16: operand larger than 2 GiB per batch entry (32-bit buffer offsets); split the batch");
+        a.a0_bytes = (unsigned)a0b;
+        a.a1_bytes = (unsigned)a1b;
+        a.w_bytes = (unsigned)wb;
+    }
 
-    // ---- tile / split heuristic: fill >= ~1 wave of the 256 CUs (2 blocks per CU resident)
+    // ---- tile / split heuristic.  Bigger tiles halve the L2->LDS traffic per FLOP; the grid should still hold
+    // >= ~2 blocks per CU (512), which small-M / deep-K problems reach through split-K (fp32 slabs + reduce).
     TileCfg cfg;
     auto tiles = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
     const int zb = d.batch;
+    const bool can_split = (d.ws != nullptr || d.split_k > 1) && d.act != VD_ACT_GEGLU && !(d.flags & VD_EPI_OUT_F32);
     if (d.act == VD_ACT_GEGLU) cfg = T128x128;
-    else if (d.N % 128 == 0 && tiles(128, 128) * zb >= 384) cfg = T128x128;
-    else if (tiles(128, 64) * zb >= 256 && d.M >= 128) cfg = T128x64;
-    else if (d.N % 128 == 0 && d.N >= 128 && d.M >= 128 && tiles(64, 64) * zb > 2048) cfg = T128x128;
+    else if (d.M < 96 || d.N < 96) cfg = T64x64;
+    else if (d.N % 128 == 0 && (tiles(128, 128) * zb >= 448 || (can_split && a.kt_total >= 32))) cfg = T128x128;
+    else if (tiles(128, 64) * zb >= 320 || (can_split && a.kt_total >= 32)) cfg = T128x64;
     else cfg = T64x64;
     int bm = 128, bn = 128;
     if (cfg == T128x64) { bm = 128; bn = 64; }
@@ -496,11 +572,11 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
 
     int nsplit = 1;
     if (d.split_k > 0) nsplit = d.split_k;
-    else if (d.ws != nullptr && d.act != VD_ACT_GEGLU) {
+    else if (can_split) {
         const int nblk = a.tiles_m * a.tiles_n * zb;
-        if (nblk < 192 && a.kt_total >= 16) {
-            nsplit = (384 + nblk - 1) / nblk;
-            if (nsplit > 16) nsplit = 16;
+        if (nblk < 384 && a.kt_total >= 16) {
+            nsplit = (640 + nblk - 1) / nblk;
+            if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
             while (nsplit > 1 && a.kt_total / nsplit < 8) --nsplit;
         }
     }
@@ -508,7 +584,8 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     if (nsplit > 1) {
         VD_REQUIRE(d.ws != nullptr, "vd_gemm_f16: split_k=%d needs a workspace", nsplit);
         VD_REQUIRE(d.act != VD_ACT_GEGLU, "vd_gemm_f16: split-K with GEGLU epilogue unsupported");
-        VD_REQUIRE(nsplit <= 16, "vd_gemm_f16: split_k=%d > 16", nsplit);
+        VD_REQUIRE(!(d.flags & VD_EPI_OUT_F32) || true, "unreachable");
+        VD_REQUIRE(nsplit <= VD_MAX_SPLIT_K, "vd_gemm_f16: split_k=%d > %d", nsplit, VD_MAX_SPLIT_K);
     }
     a.kt_per_split = (a.kt_total + nsplit - 1) / nsplit;
     nsplit = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;

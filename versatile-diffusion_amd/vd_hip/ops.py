@@ -18,6 +18,7 @@ _ws_cache = {}
 
 # ---- optional per-launch instrumentation (bench.py roofline leg; off in the product path) -------------
 _prof = None
+PROFILE_SHAPES = False
 GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64>", "gemm_f16_kernel<128,64,64,32>", "gemm_f16_kernel<64,64,32,32>")
 
 
@@ -137,17 +138,22 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
-    # split-K slabs only pay for small-M, deep-K problems; mirror the library heuristic's trigger cheaply
-    if act != ACT_GEGLU and (split_k > 1 or (M * N <= 192 * 64 * 64 and K >= 1024)):
-        nb = max(batch, 1) * 16 * M * N * 4
-        d.ws = workspace(nb, a0.device, "gemm").data_ptr()
-    else:
+    # split-K (fp32 slabs + reduce) is the library's answer to small-M / deep-K problems: ask its planner first so
+    # the workspace is sized for the split factor it will actually use
+    name, d.ws = "gemm", None
+    plan_cfg, plan_ns = ctypes.c_int(0), ctypes.c_int(1)
+    if act != ACT_GEGLU and not out_f32 and (split_k > 1 or (M * N <= 384 * 128 * 128 and K >= 1024)):
+        d.ws = 1  # any non-null value: planning only
+        _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         d.ws = None
-    name = "gemm"
+        if plan_ns.value > 1:
+            d.ws = workspace(max(batch, 1) * plan_ns.value * M * N * 4, a0.device, "gemm").data_ptr()
+            d.split_k = plan_ns.value
     if _prof is not None:
-        cfg, ns = ctypes.c_int(0), ctypes.c_int(1)
-        _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)))
-        name = GEMM_KERNEL_NAMES[cfg.value]
+        _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
+        name = GEMM_KERNEL_NAMES[plan_cfg.value]
+        if PROFILE_SHAPES:
+            name += " M=%d N=%d K=%d ks=%d split=%d%s" % (M, N, K, d.ksize, plan_ns.value, " cat" if a1 is not None else "")
     nb = max(batch, 1)
     with _Timed(name, 2.0 * nb * M * N * K, 2.0 * nb * (M * K + N * K + M * n_out)):
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
@@ -219,7 +225,7 @@ def attention(q, k, v, heads, *, scale=None, causal=False, out=None):
         out = torch.empty((B, Nq, C), dtype=torch.float16, device=q.device)
     if scale is None:
         scale = D ** -0.5
-    with _Timed("attn_fwd_kernel<%d>" % D, 4.0 * B * Nq * Nk * C, 2.0 * B * C * (2 * Nq + 2 * Nk)):
+    with _Timed(("attn_fwd_kernel<%d>" % D) + ((" Nq=%d Nk=%d B=%d" % (Nq, Nk, B)) if PROFILE_SHAPES else ""), 4.0 * B * Nq * Nk * C, 2.0 * B * C * (2 * Nq + 2 * Nk)):
         _check(lib().vd_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, q.stride(1), k.stride(1),
                                       v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                       float(scale), 1 if causal else 0, _stream()))

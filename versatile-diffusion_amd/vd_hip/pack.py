@@ -30,14 +30,15 @@ def pack_patch_weight(w, kpad=None):
 
 
 def pack_geglu(w, b=None):
-    """GEGLU proj weight [2*inner, K] (rows: values then gates) -> per 128-row group [64 value | 64 gate]."""
+    """GEGLU proj weight [2*inner, K] (rows: values then gates) -> per 64-row group [32 value | 32 gate], so the
+    value and gate of an output column land in the same lane/register of one wave's MFMA tiles."""
     two_inner, k = w.shape
     inner = two_inner // 2
     assert inner % 64 == 0, "GEGLU inner dim must be a multiple of 64"
-    val = w[:inner].reshape(inner // 64, 64, k)
-    gate = w[inner:].reshape(inner // 64, 64, k)
+    val = w[:inner].reshape(inner // 32, 32, k)
+    gate = w[inner:].reshape(inner // 32, 32, k)
     wp = torch.cat([val, gate], dim=1).reshape(two_inner, k).contiguous()
     bp = None
     if b is not None:
-        bp = torch.cat([b[:inner].reshape(-1, 64), b[inner:].reshape(-1, 64)], dim=1).reshape(-1).contiguous()
+        bp = torch.cat([b[:inner].reshape(-1, 32), b[inner:].reshape(-1, 32)], dim=1).reshape(-1).contiguous()
     return wp, bp
