@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world-size-2 gloo processes run the batch-sharding helper; the compute engine in this test is
+the CPU oracle on the tiny fixture model (tests may use the oracle; the product path itself needs the GPU)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "versatile-diffusion_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VD_QUIET="1")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from lib.model_zoo import sharded
+        from oracle import synth, vd_oracle as O
+        from vdtest_util import load_gold, meta
+        m = meta()
+        g = load_gold("unet_tiny.npz")
+        shapes = {str(k): tuple(json.loads(str(s))) for k, s in zip(g["state_keys"], g["state_shapes"])}
+        sd = synth.synth_state_dict(shapes, m["seed"])
+        sd.update(O.register_schedule())
+        plan = O.unet_plan(**m["unet2d"])
+        gen = torch.Generator().manual_seed(5)
+        c = torch.randn((B, 77, 128), generator=gen) * 0.5
+        u = torch.randn((1, 77, 128), generator=gen).repeat(B, 1, 1) * 0.5
+        ctx = [{"type": "text", "conditioning": c, "unconditional_conditioning": u}]
+
+        def sample_fn(x_T, ctxs):
+            with torch.no_grad():
+                return O.ddim_sample(sd, plan, sd["alphas_cumprod"], x_T, ctxs, 4, 7.5, global_ptr="image")[0]
+
+        def decode_fn(z):
+            with torch.no_grad():
+                return O.vae_decode(sd, "vae.image", z / 0.18215, ch_mult=m["vae"]["ddconfig"]["ch_mult"],
+                                    num_res_blocks=m["vae"]["ddconfig"]["num_res_blocks"])
+
+        imgs = sharded.sample_sharded(sample_fn, decode_fn, [B, 4, 8, 8], ctx, seed=23, device="cpu")
+        torch.save(imgs, os.path.join(out_dir, "rank%d.pt" % rank))
+        if rank == 0:  # single-process result for comparison
+            x_T = sharded.draw_initial_latent([B, 4, 8, 8], 23)
+            torch.save(decode_fn(sample_fn(x_T, ctx)), os.path.join(out_dir, "single.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 3])
+def test_batch_sharding_world2_gloo(tmp_path, B):
+    port = 29500 + (os.getpid() % 500) + B
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    single = torch.load(tmp_path / "single.pt")
+    assert r0.shape == (B, 3, 16, 16)
+    assert torch.equal(r0, r1), "all_gather must leave the same full batch on every rank"
+    # sharded == unsharded: samples are independent and the latent is drawn once and sliced
+    assert torch.allclose(r0, single, atol=1e-5)
+
+
+def test_shard_bounds():
+    sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+    from lib.model_zoo.sharded import draw_initial_latent, shard_bounds
+    for total in (1, 7, 8, 16, 33):
+        for world in (1, 2, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    a, b = draw_initial_latent([4, 4, 8, 8], 23), draw_initial_latent([4, 4, 8, 8], 23)
+    assert torch.equal(a, b)

@@ -1,0 +1,83 @@
+"""Batch-axis sharding of the sampling path across the GPUs of a node: one process per GPU (torchrun), full weight
+replica per rank, NO collective inside the DDIM loop, one all_gather of the decoded images at the end (RCCL over xGMI
+when the backend is "nccl"; gloo in the CPU tests).
+
+The reference has no inference-time multi-GPU path (app.py:279-283 uses one device); samples are independent
+(GroupNorm / LayerNorm / attention are per sample), so the batch axis shards with the CFG pair of a sample kept on one
+rank.  The full initial latent is drawn ONCE with the reference's seed rule (`torch.manual_seed(seed + 100)`,
+app.py:309) and sliced, never re-seeded per rank, so 1-GPU and N-GPU runs produce the same images.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous, balanced [lo, hi) slice of `total` samples for `rank` (earlier ranks take the remainder)."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def draw_initial_latent(shape, seed, dtype=torch.float32):
+    """Full-batch x_T from the host generator with the reference's seed convention; identical on every rank."""
+    g = torch.Generator(device="cpu").manual_seed(int(seed) + 100)
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32).to(dtype)
+
+
+def _slice_ctx(c_info, lo, hi):
+    out = dict(c_info)
+    for k in ("conditioning", "unconditional_conditioning"):
+        out[k] = c_info[k][lo:hi]
+    return out
+
+
+def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group=None, gather=True):
+    """Run `sample_fn(x_T_local, c_info_list_local) -> latents` and `decode_fn(latents) -> images` on this rank's slice
+    of the batch and all_gather the images.
+
+    shape: full-batch latent shape [B, C, h, w]; c_info_list: reference-style context dicts holding the FULL batch.
+    Returns [B, 3, H, W] images on every rank (or the local slice when gather=False)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = shape[0]
+    lo, hi = shard_bounds(B, world, rank)
+    x_T = draw_initial_latent(shape, seed)[lo:hi].to(device)
+    local_ctx = [_slice_ctx(ci, lo, hi) for ci in c_info_list]
+    if hi > lo:
+        images = decode_fn(sample_fn(x_T, local_ctx))
+    else:
+        images = None
+    if world == 1 or not gather:
+        return images
+    # ragged slices: pad to the largest slice so a single fixed-size all_gather does it
+    max_n = shard_bounds(B, world, 0)[1]
+    if images is None:
+        raise RuntimeError("rank %d got an empty slice: need batch >= world size" % rank)
+    pad = images
+    if images.shape[0] < max_n:
+        pad = torch.cat([images, images.new_zeros((max_n - images.shape[0],) + tuple(images.shape[1:]))])
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    parts = []
+    for r, b in enumerate(bufs):
+        rlo, rhi = shard_bounds(B, world, r)
+        parts.append(b[: rhi - rlo])
+    return torch.cat(parts)
+
+
+def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_scale=7.5, eta=0., group=None):
+    """t2i / multi-context sampling + kl-f8 decode of a full batch, sharded over the process group."""
+    def sample_fn(x_T, ctxs):
+        x_info = {"type": "image", "xt": x_T}
+        for ci in ctxs:
+            ci["unconditional_guidance_scale"] = guidance_scale
+        lshape = [x_T.shape[0]] + list(shape[1:])
+        if len(ctxs) == 1:
+            z, _ = sampler.sample(steps=steps, shape=lshape, x_info=x_info, c_info=ctxs[0], eta=eta, verbose=False)
+        else:
+            z, _ = sampler.sample_multicontext(steps=steps, shape=lshape, x_info=x_info, c_info_list=ctxs, eta=eta,
+                                               verbose=False)
+        return z
+
+    return sample_sharded(sample_fn, lambda z: net.vae_decode(z, which="image"), shape, c_info_list, seed, net.device,
+                          group=group)
