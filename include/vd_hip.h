@@ -123,6 +123,12 @@ int vd_cfg_ddim_step_f16(const void* x, const void* eps, const void* noise, void
                          int guided, float guidance_scale, float a_t, float a_prev, float sigma,
                          float sqrt_one_minus_at, hipStream_t stream);
 
+/* Same update with the step scalars in device memory: coef[6] = {guidance scale, 1/sqrt(a_t), sqrt(a_prev),
+ * sqrt(1 - a_prev - sigma^2), sigma, sqrt(1 - a_t)}.  Lets one captured HIP graph of a DDIM step be replayed for
+ * every step (the host only refreshes coef / the timestep tensor between replays). */
+int vd_cfg_ddim_step_dev_f16(const void* x, const void* eps, const void* noise, void* x_prev, void* pred_x0, int64_t n,
+                             int guided, const float* coef, hipStream_t stream);
+
 /* q_sample: out = sa[b] * x0 + sb[b] * noise  (lib/model_zoo/vd.py:221-224). */
 int vd_q_sample_f16(const void* x0, const void* noise, const float* sa, const float* sb, void* out, int B,
                     int64_t per_batch, hipStream_t stream);

@@ -71,6 +71,25 @@ __global__ void cfg_ddim_kernel(const f16* x, const f16* eps, const f16* noise, 
     }
 }
 
+// same update with the six step scalars read from device memory, so ONE captured HIP graph serves all DDIM steps
+// coef = {guidance scale, 1/sqrt(a_t), sqrt(a_prev), sqrt(1 - a_prev - sigma^2), sigma, sqrt(1 - a_t)}
+__global__ void cfg_ddim_dev_kernel(const f16* x, const f16* eps, const f16* noise, f16* x_prev, f16* pred_x0, size_t n,
+                                    int guided, const float* coef) {
+    const float s = coef[0], rsqrt_at = coef[1], sqrt_aprev = coef[2], dir_coef = coef[3], sigma = coef[4], sqrt_1mat = coef[5];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float e = (float)eps[i];
+        if (guided) {
+            const float ec = (float)eps[n + i];
+            e = e + s * (ec - e);
+        }
+        const float p0 = ((float)x[i] - sqrt_1mat * e) * rsqrt_at;
+        float xp = sqrt_aprev * p0 + dir_coef * e;
+        if (noise != nullptr) xp += sigma * (float)noise[i];
+        x_prev[i] = (f16)xp;
+        if (pred_x0 != nullptr) pred_x0[i] = (f16)p0;
+    }
+}
+
 __global__ void q_sample_kernel(const f16* x0, const f16* noise, const float* sa, const float* sb, f16* out, int B,
                                 size_t per_batch) {
     const size_t n = (size_t)B * per_batch;
@@ -311,6 +330,14 @@ extern "C" int vd_cfg_ddim_step_f16(const void* x, const void* eps, const void* 
                        (const f16*)eps, (const f16*)noise, (f16*)x_prev, (f16*)pred_x0, (size_t)n, guided,
                        guidance_scale, 1.0f / sqrtf(a_t), sqrtf(a_prev), sqrtf(dir2), sigma, sqrt_one_minus_at);
     return vd_check_launch("vd_cfg_ddim_step_f16");
+}
+
+extern "C" int vd_cfg_ddim_step_dev_f16(const void* x, const void* eps, const void* noise, void* x_prev, void* pred_x0,
+                                        int64_t n, int guided, const float* coef, hipStream_t stream) {
+    VD_REQUIRE(x && eps && x_prev && coef && n > 0, "vd_cfg_ddim_step_dev_f16: bad arguments");
+    hipLaunchKernelGGL(cfg_ddim_dev_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, stream, (const f16*)x,
+                       (const f16*)eps, (const f16*)noise, (f16*)x_prev, (f16*)pred_x0, (size_t)n, guided, coef);
+    return vd_check_launch("vd_cfg_ddim_step_dev_f16");
 }
 
 extern "C" int vd_q_sample_f16(const void* x0, const void* noise, const float* sa, const float* sb, void* out, int B,

@@ -22,6 +22,7 @@
 // residual fused.  Optional split-K (fp32 slabs + reduce kernel) for the small-M levels.
 #include "vd_common.h"
 #include "../../include/vd_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct GemmArgs {
     VdGemmDesc d;
     int tiles_m, tiles_n, kt_total, kt_per_split;
     unsigned a0_bytes, a1_bytes, w_bytes;  // per-batch operand extents for the buffer descriptors (< 2^31)
+    int plain;                             // 1x1, stride 1, no pad / upsample, output grid == input grid
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -144,13 +146,68 @@ __device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, fl
     epi_finish8(e, row, col, v);
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
+// Epilogue part-2 helpers; CH = 16-byte chunks per output row of the block tile (compile-time: the chunk -> (row, col)
+// split is a shift, not an integer division).
+template <int BM, int CH, int NT, int MAX_CH>
+__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int out_n0, int tid, uint4* pre_res, uint4* pre_rv) {
+    const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0);
+#pragma unroll
+    for (int k = 0; k < MAX_CH; ++k) {
+        pre_res[k] = make_uint4(0, 0, 0, 0);
+        pre_rv[k] = make_uint4(0, 0, 0, 0);
+        const int c = tid + k * NT;
+        if (vec_ok && c < BM * CH) {
+            const int r = c / CH, cc = (c % CH) * 8;
+            const int row = m0 + r, col = out_n0 + cc;
+            if (row < M && col + 8 <= e.N) {
+                if (e.flags & VD_EPI_RESIDUAL) pre_res[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
+                if (e.flags & VD_EPI_ROWVEC)
+                    pre_rv[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
+            }
+        }
+    }
+}
+
+template <int BM, int CH, int NT, int MAX_CH, int CS_LD>
+__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int out_n0, int tid, const f16* cs,
+                                             const uint4* pre_res, const uint4* pre_rv) {
+    const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
+#pragma unroll
+    for (int k = 0; k < MAX_CH; ++k) {
+        const int c = tid + k * NT;
+        if (c < BM * CH) {
+            const int r = c / CH, cc = (c % CH) * 8;
+            const int row = m0 + r, col = out_n0 + cc;
+            if (row < M && col < e.N) {
+                U4H8 t;
+                t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+                if (vec_ok && col + 8 <= e.N) {
+                    U4H8 a, b, o;
+                    a.u = pre_res[k];
+                    b.u = pre_rv[k];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + (float)b.e[i]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col) = o.u;
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (float)t.e[i];
+                    epi_finish8(e, row, col, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NT>
+__global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(WAVES_M * WAVES_N * 64 == NT, "waves must tile the block");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+    constexpr int RPP = NT / 8;  // rows staged per pass: 8 threads per 128-byte row
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
     constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
 
@@ -184,15 +241,19 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
                                                    d.a1 ? p.a1_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
 
-    // per-thread gather coordinates: 8 threads per 128-byte row, 32 rows per pass
+    // per-thread gather coordinates: 8 threads per 128-byte row, RPP rows per pass
     const int lrow = tid >> 3, lslot = tid & 7;
     int a_iy0[A_PASSES], a_ix0[A_PASSES], a_pix[A_PASSES];
     const int HWo = d.Hout * d.Wout;
     const int Hv = d.Hin << d.ups, Wv = d.Win << d.ups;
 #pragma unroll
     for (int ps = 0; ps < A_PASSES; ++ps) {
-        const int m = m0 + lrow + 32 * ps;
-        if (m < d.M) {
+        const int m = m0 + lrow + RPP * ps;
+        if (m < d.M && p.plain) {  // plain matrix / 1x1 stride-1 conv: output row == input pixel, no index division
+            a_iy0[ps] = 0;
+            a_ix0[ps] = 0;
+            a_pix[ps] = m;
+        } else if (m < d.M) {
             const int b = m / HWo;
             const int rem = m - b * HWo;
             const int oy = rem / d.Wout;
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     unsigned voff_b[B_PASSES];
 #pragma unroll
     for (int ps = 0; ps < B_PASSES; ++ps) {
-        const int n = n0 + lrow + 32 * ps;
+        const int n = n0 + lrow + RPP * ps;
         voff_b[ps] = (n < d.N) ? (unsigned)((n * d.ldw + lslot * 8) * 2) : OOB_OFFSET;
     }
 
@@ -243,14 +304,19 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
             }
         }
         const unsigned soff_a = (unsigned)cc * 2u, soff_b = (unsigned)kglob * 2u;
-        const bool kbad = ragged && (kglob + lslot * 8 >= d.K);
+        if (ragged) {  // wave-uniform: only plain matrices whose K is not a multiple of 64
+            const bool kbad = kglob + lslot * 8 >= d.K;
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            const unsigned vo = kbad ? OOB_OFFSET : voff_a[ps];
-            ra[ps] = second ? buf_load16(rs_a1, vo, soff_a) : buf_load16(rs_a0, vo, soff_a);
+            for (int ps = 0; ps < A_PASSES; ++ps) ra[ps] = buf_load16(rs_a0, kbad ? OOB_OFFSET : voff_a[ps], soff_a);
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) rb[ps] = buf_load16(rs_w, kbad ? OOB_OFFSET : voff_b[ps], soff_b);
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps)
+                ra[ps] = second ? buf_load16(rs_a1, voff_a[ps], soff_a) : buf_load16(rs_a0, voff_a[ps], soff_a);
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) rb[ps] = buf_load16(rs_w, voff_b[ps], soff_b);
         }
-#pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps) rb[ps] = buf_load16(rs_w, kbad ? OOB_OFFSET : voff_b[ps], soff_b);
     };
     // LDS addressing: (row >> 1) & 7 is the same for every 32-row pass / fragment of a lane, so each lane needs one
     // store offset and one read offset per k-step; passes and fragments are immediate offsets (32 rows = 4096 B).
@@ -259,9 +325,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         char* sa = smem + buf * STAGE_BYTES + st_off;
         char* sb = sa + BM * ROW_BYTES;
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uint4*>(sa + ps * 32 * ROW_BYTES) = ra[ps];
+        for (int ps = 0; ps < A_PASSES; ++ps) *reinterpret_cast<uint4*>(sa + ps * RPP * ROW_BYTES) = ra[ps];
 #pragma unroll
-        for (int ps = 0; ps < B_PASSES; ++ps) *reinterpret_cast<uint4*>(sb + ps * 32 * ROW_BYTES) = rb[ps];
+        for (int ps = 0; ps < B_PASSES; ++ps) *reinterpret_cast<uint4*>(sb + ps * RPP * ROW_BYTES) = rb[ps];
     };
 
     // acc[i][j] holds the TRANSPOSED 32x32 sub-tile (MFMA A operand = W rows, B operand = activation rows):
@@ -314,18 +380,36 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         store_tile(0, ra0, rb0);
     }
     __syncthreads();
-    for (int i = 0; i < nk; i += 2) {
-        if (i + 2 < nk) load_tile(kt0 + i + 2, ra0, rb0);
+    // Steady state has NO conditionals around the loads: the compiler's s_waitcnt vmcnt(N) before each LDS store
+    // then only waits for the OLDER register set and leaves the 8 newest loads in flight across the barrier.
+    int i = 0;
+    for (; i + 3 < nk; i += 2) {
+        load_tile(kt0 + i + 2, ra0, rb0);
         compute_tile(0);
-        if (i + 1 < nk) {
-            store_tile(1, ra1, rb1);
-            __syncthreads();
-            if (i + 3 < nk) load_tile(kt0 + i + 3, ra1, rb1);
-            compute_tile(1);
-            if (i + 2 < nk) store_tile(0, ra0, rb0);
-        }
+        store_tile(1, ra1, rb1);
+        __syncthreads();
+        load_tile(kt0 + i + 3, ra1, rb1);
+        compute_tile(1);
+        store_tile(0, ra0, rb0);
         __syncthreads();
     }
+    // tail: 1..3 tiles left; LDS stage 0 holds tile i, register set 1 holds tile i+1 (if any)
+    const int left = nk - i;
+    if (left >= 1) {
+        if (left >= 3) load_tile(kt0 + i + 2, ra0, rb0);
+        compute_tile(0);
+        if (left >= 2) {
+            store_tile(1, ra1, rb1);
+            __syncthreads();
+            compute_tile(1);
+            if (left >= 3) {
+                store_tile(0, ra0, rb0);
+                __syncthreads();
+                compute_tile(0);
+            }
+        }
+    }
+    __syncthreads();
 
     const EpiCtx e = make_epi(d, z);
 
@@ -373,8 +457,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     // ---- fused epilogue, part 1 (registers): + bias -> act / GEGLU -> * alpha -> fp16 into an LDS tile [BM][OUT_N]
     f16* cs = reinterpret_cast<f16*>(smem);
     const bool geglu = (d.act == VD_ACT_GEGLU);
-    const int out_bn = geglu ? BN / 2 : BN;          // output columns of this block tile
     const int out_n0 = geglu ? tn * (BN / 2) : n0;
+
+    // residual / row-vector segments of part 2 are requested NOW so their latency overlaps part 1 (the block is
+    // short-lived on the K = 320..1280 projections: every serial memory round trip shows)
+    constexpr int MAX_CH = BM * (BN / 8) / NT;
+    uint4 pre_res[MAX_CH], pre_rv[MAX_CH];
+    if (geglu) epi_prefetch<BM, BN / 16, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre_res, pre_rv);
+    else epi_prefetch<BM, BN / 8, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre_res, pre_rv);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int lrow_c = wm * WM + i * 32 + l31;
@@ -388,14 +478,17 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
                 for (int g = 0; g < 4; ++g) {
                     const int lc = wn * (WN / 2) + 8 * g + 4 * hi;     // column inside the block's output tile
                     const int pn = n0 + wn * WN + 8 * g + 4 * hi;      // packed weight row of the value element
-                    U2H4 o;
+                    U2H4 bv, bg, o;
+                    bv.u = make_uint2(0, 0);
+                    bg.u = make_uint2(0, 0);
+                    if (e.flags & VD_EPI_BIAS) {
+                        bv.u = *reinterpret_cast<const uint2*>(e.bias + pn);
+                        bg.u = *reinterpret_cast<const uint2*>(e.bias + pn + 32);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v = acc[i][0][g * 4 + q], gt = acc[i][1][g * 4 + q];
-                        if (e.flags & VD_EPI_BIAS) {
-                            v += (float)e.bias[pn + q];
-                            gt += (float)e.bias[pn + 32 + q];
-                        }
+                        const float v = acc[i][0][g * 4 + q] + (float)bv.e[q];
+                        const float gt = acc[i][1][g * 4 + q] + (float)bg.e[q];
                         o.e[q] = (f16)(v * vd_gelu_erf(gt) * e.alpha);
                     }
                     *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
@@ -422,8 +515,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
                         }
                     }
                     U2H4 o;
+                    if (e.act == VD_ACT_NONE) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o.e[q] = (f16)(apply_act(e.act, acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                        for (int q = 0; q < 4; ++q) o.e[q] = (f16)((acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o.e[q] = (f16)(apply_act(e.act, acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                    }
                     *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
                 }
         }
@@ -431,19 +529,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     __syncthreads();
 
     // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
-    const int ch_per_row = out_bn / 8;
-    for (int c = tid; c < BM * ch_per_row; c += 256) {
-        const int r = c / ch_per_row, cc = (c - r * ch_per_row) * 8;
-        const int row = m0 + r, col = out_n0 + cc;
-        if (row < d.M && col < e.N) {
-            U4H8 t;
-            t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (float)t.e[i];
-            epi_finish8(e, row, col, v);
-        }
-    }
+    if (geglu) epi_writeout<BM, BN / 16, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre_res, pre_rv);
+    else epi_writeout<BM, BN / 8, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre_res, pre_rv);
 }
 
 // Sum the split-K slabs and run the fused epilogue. One thread per 8 output columns.
@@ -475,19 +562,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NT>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
     constexpr int EPI_BYTES = BM * (BN + 8) * 2;
     constexpr int LDS = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT>), grid, dim3(NT), LDS, stream, a);
     return vd_check_launch("vd_gemm_f16");
 }
 
@@ -500,7 +587,7 @@ extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
 }
 
 namespace {
-enum TileCfg { T128x128 = 0, T128x64 = 1, T64x64 = 2 };
+enum TileCfg { T128x128 = 0, T128x64 = 1, T64x64 = 2, T128x128w8 = 3, T128x64w8 = 4 };
 
 // validate + normalise the descriptor and pick tile shape / split factor
 int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) {
@@ -551,6 +638,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         a.a0_bytes = (unsigned)a0b;
         a.a1_bytes = (unsigned)a1b;
         a.w_bytes = (unsigned)wb;
+        a.plain = (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.ups == 0 && d.Hin * d.Win == d.Hout * d.Wout) ? 1 : 0;
     }
 
     // ---- tile / split heuristic.  Bigger tiles halve the L2->LDS traffic per FLOP; the grid should still hold
@@ -561,11 +649,15 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     const bool can_split = (d.ws != nullptr || d.split_k > 1) && d.act != VD_ACT_GEGLU && !(d.flags & VD_EPI_OUT_F32);
     if (d.act == VD_ACT_GEGLU) cfg = T128x128;
     else if (d.M < 96 || d.N < 96) cfg = T64x64;
-    else if (d.N % 128 == 0 && (tiles(128, 128) * zb >= 448 || (can_split && a.kt_total >= 32))) cfg = T128x128;
-    else if (tiles(128, 64) * zb >= 320 || (can_split && a.kt_total >= 32)) cfg = T128x64;
+    else if (d.N % 128 == 0 && (tiles(128, 128) * zb >= 448 || (can_split && a.kt_total >= 64))) cfg = T128x128;
+    else if (tiles(128, 64) * zb >= 320 || (can_split && a.kt_total >= 64)) cfg = T128x64;
     else cfg = T64x64;
+    {   // developer override for tile experiments: VD_GEMM_TILE=0|1|2 (never set in production runs)
+        static const char* ov = getenv("VD_GEMM_TILE");
+        if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3')) cfg = (TileCfg)(ov[0] - '0');
+    }
     int bm = 128, bn = 128;
-    if (cfg == T128x64) { bm = 128; bn = 64; }
+    if (cfg == T128x64 || cfg == T128x64w8) { bm = 128; bn = 64; }
     if (cfg == T64x64) { bm = 64; bn = 64; }
     a.tiles_m = (d.M + bm - 1) / bm;
     a.tiles_n = (d.N + bn - 1) / bn;
@@ -574,10 +666,10 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     if (d.split_k > 0) nsplit = d.split_k;
     else if (can_split) {
         const int nblk = a.tiles_m * a.tiles_n * zb;
-        if (nblk < 384 && a.kt_total >= 16) {
+        if (nblk < 384 && a.kt_total >= 32) {  // below K = 2048 the slab round trip + reduce launch costs more than it buys
             nsplit = (640 + nblk - 1) / nblk;
             if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
-            while (nsplit > 1 && a.kt_total / nsplit < 8) --nsplit;
+            while (nsplit > 1 && a.kt_total / nsplit < 12) --nsplit;
         }
     }
     if (nsplit > a.kt_total) nsplit = a.kt_total;
@@ -614,9 +706,11 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int zb = d.batch;
 
     switch (cfg) {
-        case T128x128: rc = launch_cfg<128, 128, 64, 64>(a, nsplit, stream); break;
-        case T128x64: rc = launch_cfg<128, 64, 64, 32>(a, nsplit, stream); break;
-        default: rc = launch_cfg<64, 64, 32, 32>(a, nsplit, stream); break;
+        case T128x128: rc = launch_cfg<128, 128, 64, 64, 256>(a, nsplit, stream); break;
+        case T128x64: rc = launch_cfg<128, 64, 64, 32, 256>(a, nsplit, stream); break;
+        case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512>(a, nsplit, stream); break;
+        case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512>(a, nsplit, stream); break;
+        default: rc = launch_cfg<64, 64, 32, 32, 256>(a, nsplit, stream); break;
     }
     if (rc != VD_OK) return rc;
     if (nsplit > 1) {

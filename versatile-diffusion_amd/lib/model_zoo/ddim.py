@@ -1,11 +1,15 @@
 """DDIM sampler with the reference's API (lib/model_zoo/ddim.py:10-298 there): `DDIMSampler(model).sample(...)`
 and `.sample_multicontext(...)` with the same arguments, dict protocol and return values.
 
-What changed underneath: the CFG combine and the DDIM update are ONE elementwise kernel fed with host-side
-schedule scalars (the reference issues ~10 tiny kernels and three device->host syncs per step), the CFG-doubled
-context batch is assembled once instead of every step, and the step-invariant context K/V projections of all 16
-cross-attention layers are computed once per sample() call and reused by every step.
+What changed underneath: the CFG combine and the DDIM update are ONE elementwise kernel (the reference issues ~10
+tiny kernels and three device->host syncs per step), the CFG-doubled context batch is assembled once instead of every
+step, the step-invariant context K/V projections of all 16 cross-attention layers are computed once per sample() call,
+and -- because every launch goes to torch's current stream with static shapes -- the whole step (UNet forward + update,
+~450 kernel launches) is captured once into a HIP graph and replayed for the remaining steps; between replays the host
+only refreshes a 6-float coefficient vector and the timestep tensor.  Set VD_DDIM_GRAPH=0 to run every step eagerly.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +24,7 @@ class DDIMSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
+        self.use_graph = os.environ.get("VD_DDIM_GRAPH", "1") != "0"
 
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
@@ -103,17 +108,92 @@ class DDIMSampler(object):
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         x = x_info["x"].to(torch.float16).contiguous()
-        pred_x0 = None
-        for i, step in enumerate(time_range):
-            index = total_steps - i - 1
-            x, pred_x0 = self._step(x, x_info, c_info_list, int(step), index, guided, scale, temperature, _single)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates["pred_xt"].append(x.to(dtype))
-                intermediates["pred_x0"].append(pred_x0.to(dtype))
+        eta_zero = bool(np.all(self.ddim_sigmas[:total_steps] == 0.))
+        if x.is_cuda and eta_zero and total_steps > 0:
+            x, pred_x0 = self._loop_static(x, x_info, c_info_list, time_range, total_steps, guided, scale, _single,
+                                           log_every_t, intermediates, dtype)
+        else:
+            pred_x0 = None
+            for i, step in enumerate(time_range):
+                index = total_steps - i - 1
+                x, pred_x0 = self._step(x, x_info, c_info_list, int(step), index, guided, scale, temperature, _single)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    intermediates["pred_xt"].append(x.to(dtype))
+                    intermediates["pred_x0"].append(pred_x0.to(dtype))
         for ci in c_info_list:
             ci.pop("kv_cache", None)
         x_info["x"] = x.to(dtype)
         return x_info["x"], intermediates
+
+    def _coef_table(self, total_steps, scale, device):
+        """[S, 6] fp32 device table of {scale, 1/sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma, sqrt(1-a_t)}."""
+        a_t = self.ddim_alphas[:total_steps].astype(np.float64)
+        a_prev = self.ddim_alphas_prev[:total_steps].astype(np.float64)
+        sig = self.ddim_sigmas[:total_steps].astype(np.float64)
+        tab = np.stack([np.full_like(a_t, float(scale)), 1.0 / np.sqrt(a_t), np.sqrt(a_prev),
+                        np.sqrt(np.maximum(1.0 - a_prev - sig ** 2, 0.0)), sig,
+                        self.ddim_sqrt_one_minus_alphas[:total_steps].astype(np.float64)], axis=1)
+        return torch.from_numpy(tab.astype(np.float32)).to(device)
+
+    def _loop_static(self, x, x_info, c_info_list, time_range, total_steps, guided, scale, single, log_every_t,
+                     intermediates, dtype):
+        """eta = 0 loop on static buffers: step 0 runs eagerly (fills weight-pack and K/V caches), is then captured
+        into a HIP graph, and the graph is replayed for the remaining steps."""
+        dev = x.device
+        b = x.shape[0]
+        nb = 2 * b if guided else b
+        xs = x.clone()
+        x_next, p0 = torch.empty_like(xs), torch.empty_like(xs)
+        ts = torch.empty((nb,), device=dev, dtype=torch.long)
+        coef = torch.empty((6,), device=dev, dtype=torch.float32)
+        table = self._coef_table(total_steps, scale, dev)
+        steps_dev = torch.from_numpy(np.ascontiguousarray(time_range).astype(np.int64)).to(dev)
+
+        def body():
+            x_in = torch.cat([xs, xs]) if guided else xs
+            xi = {"type": x_info["type"], "x": x_in}
+            if single:
+                eps = self.model.apply_model(xi, ts, c_info_list[0])
+            else:
+                eps = self.model.apply_model_multicontext(xi, ts, c_info_list)
+            ops.cfg_ddim_step_dev(xs, eps.contiguous(), coef, guided=guided, x_prev=x_next, pred_x0=p0)
+            xs.copy_(x_next)
+
+        graph = None
+        for i in range(total_steps):
+            index = total_steps - i - 1
+            ts.copy_(steps_dev[i].expand(nb))       # device-side refresh, no host sync
+            coef.copy_(table[index])
+            if i == 0 or not self.use_graph:
+                body()
+            elif graph is None:
+                graph = self._capture(body)
+                if graph is None:
+                    body()
+                else:
+                    graph.replay()
+            else:
+                graph.replay()
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["pred_xt"].append(xs.to(dtype).clone())
+                intermediates["pred_x0"].append(p0.to(dtype).clone())
+        return xs, p0
+
+    def _capture(self, body):
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g, stream=s):
+                    body()
+            torch.cuda.current_stream().wait_stream(s)
+            ops.drop_workspaces(s.cuda_stream)
+            return g
+        except Exception as e:  # stay on the (same) HIP kernels, just launched eagerly
+            print("[DDIMSampler] HIP graph capture unavailable (%s); running steps eagerly" % e)
+            self.use_graph = False
+            return None
 
     def _step(self, x, x_info, c_info_list, step, index, guided, scale, temperature, single):
         """One p_sample_ddim (reference ddim.py:129-171 / 244-298) on the fp16 device latent `x` [B,C,H,W]."""

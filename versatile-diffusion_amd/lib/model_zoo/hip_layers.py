@@ -53,8 +53,10 @@ class Conv2d(nn.Conv2d, PackCache):
             return pack.pack_conv_weight(w), _h(self.bias)
         return self._packed("w", (self.weight, self.bias), build)
 
-    def forward(self, x, x1=None, ups=0, pad_hi=None, in_layout="nhwc", in_scale=1.0, in_shift=0.0, **epi):
+    def forward(self, x, x1=None, ups=0, pad_hi=None, in_layout="nhwc", in_scale=1.0, in_shift=0.0, bias=None, **epi):
         w, b = self._w()
+        if bias is not None:  # caller-supplied (pre-combined) bias vector
+            b = bias
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
         cin = self.in_channels
         if cin % 64 != 0:

@@ -40,7 +40,8 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
 
     ctx_specs: list of (context_blocks, context [B, L, Dc], ratio, kv_cache or None), one per context type.
     x: NCHW latent; returns NCHW eps in fp16."""
-    d_iter = iter(data_net.data_blocks)
+    d_iter = iter(enumerate(data_net.data_blocks))
+    emb_outs = data_net.precompute_emb(emb_silu) if hasattr(data_net, "precompute_emb") else {}
     c_iters = [iter(spec[0]) for spec in ctx_specs]
     ratios = np.array([float(spec[2]) for spec in ctx_specs], dtype=np.float64)
     ratios = ratios / ratios.sum()
@@ -70,7 +71,8 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
     h = x
     for ltype in data_net.i_order + data_net.m_order:
         if ltype == "d":
-            h = next(d_iter)(h, emb_silu, None)
+            di, blk = next(d_iter)
+            h = blk(h, emb_silu, None, emb_out=emb_outs.get(di))
         elif ltype == "c":
             h = run_context(h)
         elif ltype == "save_hidden_feature":
@@ -80,7 +82,8 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
         if ltype == "load_hidden_feature":
             skip = hs.pop()
         elif ltype == "d":
-            h = next(d_iter)(h, emb_silu, None, skip=skip)
+            di, blk = next(d_iter)
+            h = blk(h, emb_silu, None, skip=skip, emb_out=emb_outs.get(di))
             skip = None
         elif ltype == "c":
             h = run_context(h)

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "vd_softmax_rows_f32_f16": (_I, [_P, _P, _L, _I, _P]),
     "vd_timestep_embedding_f16": (_I, [_P, _P, _I, _I, _F, _P]),
     "vd_cfg_ddim_step_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    "vd_cfg_ddim_step_dev_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "vd_q_sample_f16": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "vd_nchw_to_nhwc_f16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vd_nhwc_to_nchw_f16": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P]),

@@ -19,7 +19,8 @@ _ws_cache = {}
 # ---- optional per-launch instrumentation (bench.py roofline leg; off in the product path) -------------
 _prof = None
 PROFILE_SHAPES = False
-GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64>", "gemm_f16_kernel<128,64,64,32>", "gemm_f16_kernel<64,64,32,32>")
+GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64,256>", "gemm_f16_kernel<128,64,64,32,256>", "gemm_f16_kernel<64,64,32,32,256>",
+                     "gemm_f16_kernel<128,128,32,64,512>", "gemm_f16_kernel<128,64,32,32,512>")
 
 
 def profile_begin():
@@ -86,6 +87,12 @@ def workspace(nbytes, device, tag="ws"):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def drop_workspaces(stream_id):
+    """Forget scratch buffers keyed to a (capture) stream; a captured graph keeps its own pool alive."""
+    for k in [k for k in _ws_cache if k[1] == stream_id]:
+        del _ws_cache[k]
 
 
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
@@ -260,6 +267,17 @@ def cfg_ddim_step(x, eps, *, guided, guidance_scale, a_t, a_prev, sigma, sqrt_on
     _check(lib().vd_cfg_ddim_step_f16(_ptr(x), _ptr(eps), _ptr(noise), _ptr(x_prev), _ptr(pred_x0), n, 1 if guided else 0,
                                       float(guidance_scale), float(a_t), float(a_prev), float(sigma),
                                       float(sqrt_one_minus_at), _stream()))
+    return x_prev, pred_x0
+
+
+def cfg_ddim_step_dev(x, eps, coef, *, guided, x_prev, pred_x0=None, noise=None):
+    """CFG + DDIM update with the step scalars in a device fp32[6] tensor; writes into caller-owned buffers."""
+    _req(x, "x"); _req(eps, "eps"); _req(noise, "noise"); _req(coef, "coef", torch.float32); _req(x_prev, "x_prev"); _req(pred_x0, "pred_x0")
+    n = x.numel()
+    if eps.numel() != (2 * n if guided else n):
+        raise VdHipError("eps has %d elements, expected %d" % (eps.numel(), 2 * n if guided else n))
+    _check(lib().vd_cfg_ddim_step_dev_f16(_ptr(x), _ptr(eps), _ptr(noise), _ptr(x_prev), _ptr(pred_x0), n,
+                                          1 if guided else 0, _ptr(coef), _stream()))
     return x_prev, pred_x0
 
 
