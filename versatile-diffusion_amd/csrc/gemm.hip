@@ -26,6 +26,7 @@
 
 namespace {
 
+constexpr int VD_GEMM_DEFAULT_DMA = 2;  // LDS-DMA, two stages (measured: +8..15 % over register staging; 3 stages lose occupancy)
 constexpr int BK = 64;           // K tile (halfs); one LDS row = 128 bytes = 8 x 16-byte slots
 constexpr int ROW_BYTES = BK * 2;
 
@@ -42,6 +43,39 @@ constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_r
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));  // stride 0, no swizzle
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// 16 bytes per lane straight from global memory into LDS (no VGPR round trip, no ds_write): LDS address =
+// lds_base (wave-uniform, via M0) + lane * 16; the global side keeps the per-lane offset, so the XOR swizzle of the
+// LDS image is applied by permuting WHICH 16-byte slot each lane fetches.  Issued through inline asm on purpose:
+// hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read that follows (it cannot prove the DMA
+// targets another stage), serialising load and MFMA phases.  Completion is tracked by hand (vmcnt) in the K loop.
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -199,7 +233,7 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NT>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES>
 __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -371,45 +405,131 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
         }
     };
 
+    if constexpr (STAGES == 0) {
     // ---- main loop: two register sets -> global loads run two K tiles ahead of the MFMAs, LDS double buffer,
-    // one barrier per K tile.
-    uint4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
-    if (nk > 0) {
-        load_tile(kt0, ra0, rb0);
-        if (nk > 1) load_tile(kt0 + 1, ra1, rb1);
-        store_tile(0, ra0, rb0);
-    }
-    __syncthreads();
-    // Steady state has NO conditionals around the loads: the compiler's s_waitcnt vmcnt(N) before each LDS store
-    // then only waits for the OLDER register set and leaves the 8 newest loads in flight across the barrier.
-    int i = 0;
-    for (; i + 3 < nk; i += 2) {
-        load_tile(kt0 + i + 2, ra0, rb0);
-        compute_tile(0);
-        store_tile(1, ra1, rb1);
+        // one barrier per K tile.
+        uint4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
+        if (nk > 0) {
+            load_tile(kt0, ra0, rb0);
+            if (nk > 1) load_tile(kt0 + 1, ra1, rb1);
+            store_tile(0, ra0, rb0);
+        }
         __syncthreads();
-        load_tile(kt0 + i + 3, ra1, rb1);
-        compute_tile(1);
-        store_tile(0, ra0, rb0);
-        __syncthreads();
-    }
-    // tail: 1..3 tiles left; LDS stage 0 holds tile i, register set 1 holds tile i+1 (if any)
-    const int left = nk - i;
-    if (left >= 1) {
-        if (left >= 3) load_tile(kt0 + i + 2, ra0, rb0);
-        compute_tile(0);
-        if (left >= 2) {
+        // Steady state has NO conditionals around the loads: the compiler's s_waitcnt vmcnt(N) before each LDS store
+        // then only waits for the OLDER register set and leaves the 8 newest loads in flight across the barrier.
+        int i = 0;
+        for (; i + 3 < nk; i += 2) {
+            load_tile(kt0 + i + 2, ra0, rb0);
+            compute_tile(0);
             store_tile(1, ra1, rb1);
             __syncthreads();
+            load_tile(kt0 + i + 3, ra1, rb1);
             compute_tile(1);
-            if (left >= 3) {
-                store_tile(0, ra0, rb0);
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+        // tail: 1..3 tiles left; LDS stage 0 holds tile i, register set 1 holds tile i+1 (if any)
+        const int left = nk - i;
+        if (left >= 1) {
+            if (left >= 3) load_tile(kt0 + i + 2, ra0, rb0);
+            compute_tile(0);
+            if (left >= 2) {
+                store_tile(1, ra1, rb1);
                 __syncthreads();
-                compute_tile(0);
+                compute_tile(1);
+                if (left >= 3) {
+                    store_tile(0, ra0, rb0);
+                    __syncthreads();
+                    compute_tile(0);
+                }
             }
         }
+        __syncthreads();
+    } else {
+        // ---- main loop, LDS-DMA form: STAGES LDS buffers, tiles are DMA'd STAGES-1 ahead, one barrier per K tile
+        constexpr int LPT = A_PASSES + B_PASSES;  // DMA instructions per thread and tile
+        const i32x4 ws_a0 = make_rsrc_words(reinterpret_cast<const f16*>(d.a0) + (size_t)z * d.stride_a, p.a0_bytes);
+        const i32x4 ws_a1 = make_rsrc_words(d.a1 ? reinterpret_cast<const f16*>(d.a1) + (size_t)z * d.stride_a : d.a0,
+                                            d.a1 ? p.a1_bytes : 0u);
+        const i32x4 ws_w = make_rsrc_words(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const unsigned wave_dst = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 8 * ROW_BYTES);  // 8 rows per wave and pass
+        const int sw_slot = lslot ^ ((lrow >> 1) & 7);  // the lane fetches the logical slot that lives at its physical slot
+        unsigned dvoff_b[B_PASSES];
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            const int n = n0 + lrow + RPP * ps;
+            dvoff_b[ps] = (n < d.N) ? (unsigned)((n * d.ldw + sw_slot * 8) * 2) : OOB_OFFSET;
+        }
+        unsigned dvoff_a[A_PASSES];
+        // (tap, channel offset) of the next tile to issue, advanced incrementally: no per-tile integer division
+        int n_tap = (kt0 * BK) / ctot;
+        int n_cc = kt0 * BK - n_tap * ctot;
+        int n_ky = n_tap / d.ksize, n_kx = n_tap - n_ky * d.ksize;
+        bool seg_dirty = true;
+        bool n_second = false;
+        auto issue_tile = [&](int t, int buf) {
+            const bool second = n_cc >= d.c0;
+            if (second != n_second) { n_second = second; seg_dirty = true; }
+            if (seg_dirty) {  // wave-uniform: first tile, new tap, or switch to the concatenated source
+                seg_dirty = false;
+                const int ld = second ? d.lda1 : d.lda0;
+#pragma unroll
+                for (int ps = 0; ps < A_PASSES; ++ps) {
+                    const int iy = a_iy0[ps] + n_ky, ix = a_ix0[ps] + n_kx;
+                    const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+                    const int pix = a_pix[ps] + (iy >> d.ups) * d.Win + (ix >> d.ups);
+                    dvoff_a[ps] = ok ? (unsigned)((pix * ld + sw_slot * 8) * 2) : OOB_OFFSET;
+                }
+            }
+            const int kglob = t * BK;
+            const unsigned soff_a = (unsigned)((second ? n_cc - d.c0 : n_cc) * 2);
+            const unsigned soff_b = (unsigned)(kglob * 2);
+            const unsigned dst_a = lds0 + (unsigned)(buf * STAGE_BYTES) + wave_dst;
+            const unsigned dst_b = dst_a + BM * ROW_BYTES;
+            const i32x4 ra_src = second ? ws_a1 : ws_a0;
+            if (ragged) {
+                const bool kbad = kglob + sw_slot * 8 >= d.K;
+#pragma unroll
+                for (int ps = 0; ps < A_PASSES; ++ps)
+                    dma16(ra_src, dst_a + ps * RPP * ROW_BYTES, kbad ? OOB_OFFSET : dvoff_a[ps], soff_a);
+#pragma unroll
+                for (int ps = 0; ps < B_PASSES; ++ps)
+                    dma16(ws_w, dst_b + ps * RPP * ROW_BYTES, kbad ? OOB_OFFSET : dvoff_b[ps], soff_b);
+            } else {
+#pragma unroll
+                for (int ps = 0; ps < A_PASSES; ++ps) dma16(ra_src, dst_a + ps * RPP * ROW_BYTES, dvoff_a[ps], soff_a);
+#pragma unroll
+                for (int ps = 0; ps < B_PASSES; ++ps) dma16(ws_w, dst_b + ps * RPP * ROW_BYTES, dvoff_b[ps], soff_b);
+            }
+            // advance to the next K tile
+            n_cc += BK;
+            if (n_cc >= ctot) {
+                n_cc -= ctot;
+                ++n_tap;
+                ++n_kx;
+                if (n_kx == d.ksize) { n_kx = 0; ++n_ky; }
+                seg_dirty = true;
+            }
+        };
+        constexpr int D = STAGES - 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < nk) issue_tile(kt0 + j, j);
+        int cbuf = 0, ibuf = D % STAGES;
+        for (int i = 0; i < nk; ++i) {
+            // tile i must have landed; in steady state the D-1 younger tiles stay in flight across the barrier
+            if (i + D - 1 < nk) wait_vmcnt<LPT * (D - 1)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
+            if (i + D < nk) issue_tile(kt0 + i + D, ibuf);
+            compute_tile(cbuf);
+            cbuf = (cbuf + 1 == STAGES) ? 0 : cbuf + 1;
+            ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const EpiCtx e = make_epi(d, z);
 
@@ -562,19 +682,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NT>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
     constexpr int EPI_BYTES = BM * (BN + 8) * 2;
-    constexpr int LDS = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int NST = STAGES == 0 ? 2 : STAGES;
+    constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT>), grid, dim3(NT), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>), grid, dim3(NT), LDS, stream, a);
     return vd_check_launch("vd_gemm_f16");
 }
 
@@ -647,7 +768,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     auto tiles = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
     const int zb = d.batch;
     const bool can_split = (d.ws != nullptr || d.split_k > 1) && d.act != VD_ACT_GEGLU && !(d.flags & VD_EPI_OUT_F32);
-    if (d.act == VD_ACT_GEGLU) cfg = T128x128;
+    if (d.act == VD_ACT_GEGLU) cfg = T128x128w8;  // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others
     else if (d.M < 96 || d.N < 96) cfg = T64x64;
     else if (d.N % 128 == 0 && (tiles(128, 128) * zb >= 448 || (can_split && a.kt_total >= 64))) cfg = T128x128;
     else if (tiles(128, 64) * zb >= 320 || (can_split && a.kt_total >= 64)) cfg = T128x64;
@@ -705,13 +826,19 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const VdGemmDesc& d = a.d;
     const int zb = d.batch;
 
+    static const char* dma_env = getenv("VD_GEMM_DMA");  // developer switch: 0 = register staging, 2 = LDS-DMA (3 stages measured slower: occupancy)
+    const int dma = dma_env ? (dma_env[0] - '0') : VD_GEMM_DEFAULT_DMA;
+#define VD_LAUNCH(BM_, BN_, WM_, WN_, NT_)                                                        \
+    (dma == 2 ? launch_cfg<BM_, BN_, WM_, WN_, NT_, 2>(a, nsplit, stream)                         \
+              : launch_cfg<BM_, BN_, WM_, WN_, NT_, 0>(a, nsplit, stream))
     switch (cfg) {
-        case T128x128: rc = launch_cfg<128, 128, 64, 64, 256>(a, nsplit, stream); break;
-        case T128x64: rc = launch_cfg<128, 64, 64, 32, 256>(a, nsplit, stream); break;
-        case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512>(a, nsplit, stream); break;
-        case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512>(a, nsplit, stream); break;
-        default: rc = launch_cfg<64, 64, 32, 32, 256>(a, nsplit, stream); break;
+        case T128x128: rc = VD_LAUNCH(128, 128, 64, 64, 256); break;
+        case T128x64: rc = VD_LAUNCH(128, 64, 64, 32, 256); break;
+        case T128x128w8: rc = VD_LAUNCH(128, 128, 32, 64, 512); break;
+        case T128x64w8: rc = VD_LAUNCH(128, 64, 32, 32, 512); break;
+        default: rc = VD_LAUNCH(64, 64, 32, 32, 256); break;
     }
+#undef VD_LAUNCH
     if (rc != VD_OK) return rc;
     if (nsplit > 1) {
         const size_t total = (size_t)d.M * ((d.N + 7) / 8);
