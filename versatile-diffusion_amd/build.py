@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("VD_EXTRA_DEFS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

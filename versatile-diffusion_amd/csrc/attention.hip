@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef VD_ATTN_MINW
+#define VD_ATTN_MINW 1
+#endif
 constexpr int KV = 64;    // keys per tile
 constexpr int QB = 128;   // queries per block (4 waves x 32)
 constexpr int VROW = KV + 4;  // V^T row stride in halfs: 136 bytes -> conflict-free ds_read_b64
@@ -37,18 +40,21 @@ struct AttnArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int KS = (D + 15) / 16;       // k-steps of the QK^T MFMA
     constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T
     constexpr int KROW = KS * 16 + 8;       // K row stride in halfs (odd number of 16-byte slots)
     constexpr int KCH = KS * 2;             // 16-byte chunks per staged K row (zero padded past D)
     constexpr int VCH = D / 8;              // 16-byte chunks per V row
     constexpr int K_ITERS = (KV * KCH + 255) / 256;
-    constexpr int V_ITERS = (KV * VCH + 255) / 256;
+    constexpr int VITEMS = (KV / 2) * VCH;  // one item = 2 adjacent keys x 8 channels -> 8 dword LDS writes
+    constexpr int V_ITERS = (VITEMS + 255) / 256;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+    // double-buffered K / V^T tiles (one barrier per tile) where two copies fit the 64 KiB static LDS limit
+    constexpr int TILE_HALFS = KV * KROW + DB * 32 * VROW;
+    constexpr int NBUF = (2 * TILE_HALFS * 2 <= 60 * 1024) ? 2 : 1;
 
-    __shared__ __attribute__((aligned(16))) f16 Ks[KV * KROW];
-    __shared__ __attribute__((aligned(16))) f16 Vt[DB * 32 * VROW];
+    __shared__ __attribute__((aligned(16))) f16 lds_all[NBUF * TILE_HALFS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -72,8 +78,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const f16* vp = p.v + (size_t)b * p.sv + h * D;
     f16* op = p.o + (size_t)b * p.so + h * D;
 
-    // zero V^T once (rows d >= D and key padding must be finite)
-    for (int i = tid; i < DB * 32 * VROW / 2; i += 256) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+    // zero the tiles once (V^T rows d >= D must be finite)
+    for (int i = tid; i < NBUF * TILE_HALFS / 2; i += 256) reinterpret_cast<uint32_t*>(lds_all)[i] = 0u;
 
     // ---- Q fragments: B operand, lane = (query l31, k-half hi), 8 consecutive d per k-step
     const int qrow = qb * QB + wave * 32 + l31;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         ntiles = min(ntiles, last_q / KV + 1);
     }
 
-    uint4 rk[K_ITERS], rv[V_ITERS];
+    uint4 rk[K_ITERS], rv[V_ITERS][2];
     auto load_kv = [&](int t) {
         const int key0 = t * KV;
 #pragma unroll
@@ -115,14 +121,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int it = 0; it < V_ITERS; ++it) {
             const int c = tid + it * 256;
-            const int r = c / VCH, ch = c - r * VCH;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < KV * VCH && key0 + r < p.Nk)
-                v = *reinterpret_cast<const uint4*>(vp + (size_t)(key0 + r) * p.ldv + ch * 8);
-            rv[it] = v;
+            const int kpair = c % (KV / 2), ch = c / (KV / 2);  // key pair fastest: conflict-free transposed writes
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int key = key0 + 2 * kpair + h2;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < VITEMS && key < p.Nk) v = *reinterpret_cast<const uint4*>(vp + (size_t)key * p.ldv + ch * 8);
+                rv[it][h2] = v;
+            }
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
+        f16* Ks = lds_all + buf * TILE_HALFS;
+        f16* Vt = Ks + KV * KROW;
 #pragma unroll
         for (int it = 0; it < K_ITERS; ++it) {
             const int c = tid + it * 256;
@@ -132,35 +143,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int it = 0; it < V_ITERS; ++it) {
             const int c = tid + it * 256;
-            const int r = c / VCH, ch = c - r * VCH;
-            if (c < KV * VCH) {
-                U4H8 t;
-                t.u = rv[it];
+            const int kpair = c % (KV / 2), ch = c / (KV / 2);
+            if (c < VITEMS) {
+                U4H8 a, b;
+                a.u = rv[it][0];
+                b.u = rv[it][1];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VROW + r] = t.e[i];
+                for (int i = 0; i < 8; ++i) {  // V^T[d][2*kpair .. +1] as one dword: lanes -> consecutive banks
+                    f16x2 pr;
+                    pr[0] = a.e[i];
+                    pr[1] = b.e[i];
+                    *reinterpret_cast<f16x2*>(Vt + (ch * 8 + i) * VROW + 2 * kpair) = pr;
+                }
             }
         }
     };
 
-    if (ntiles > 0) load_kv(0);
+    if (ntiles > 0) {
+        load_kv(0);
+        __syncthreads();  // orders the zero fill
+        store_kv(0);
+    }
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();  // previous tile fully consumed (also orders the V^T zero fill)
-        store_kv();
-        __syncthreads();
+        const int cur = (NBUF == 2) ? (t & 1) : 0;
+        const f16* Ks = lds_all + cur * TILE_HALFS;
+        const f16* Vt = Ks + KV * KROW;
         if (t + 1 < ntiles) load_kv(t + 1);  // in flight under the MFMAs below
 
         // ---- S^T tiles (keys x queries)
         f32x16 st[KV / 32];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 U4H8 a;
                 a.u = *reinterpret_cast<const uint4*>(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], st[kt], 0, 0, 0);
+                // first k-step takes C = 0 as an inline constant: no 16-register zero fill per tile
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? zero16 : st[kt], 0, 0, 0);
             }
+        }
+
+        // V^T fragments of this tile are requested BEFORE the softmax math so the LDS latency hides under the VALU
+        // work instead of stalling each P.V MFMA (affordable for head dims <= 96: 16 / 24 fragment registers pairs)
+        constexpr bool PREFETCH_V = false;  // measured: +14 VGPRs drop 3 -> 2 waves/SIMD and cost 13 %; occupancy wins
+        uint2 vfrag[PREFETCH_V ? KV / 32 : 1][2][PREFETCH_V ? DB : 1][2];
+        if constexpr (PREFETCH_V) {
+#pragma unroll
+            for (int kt = 0; kt < KV / 32; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < DB; ++i) {
+                        const f16* vr = Vt + (i * 32 + l31) * VROW + kt * 32 + 16 * s2 + 4 * hi;
+                        vfrag[kt][s2][i][0] = *reinterpret_cast<const uint2*>(vr);
+                        vfrag[kt][s2][i][1] = *reinterpret_cast<const uint2*>(vr + 8);
+                    }
         }
 
         // ---- online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
@@ -180,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[kt][r]), st[kt][r + 1]);  // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float ms = mx * p.scale_log2;  // running max is tracked in scaled (log2) units
         // Deferred rescale: the accumulators are only rescaled when some row's max grew by more than RESCALE_THR
@@ -196,17 +235,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             m_run = m_new;
         }
         const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
-        float psum = 0.f;
+        // the softmax body is VALU-issue bound (3 waves per SIMD share one VALU port): packed fp32 math for the
+        // scale/shift and the row sum halves those instruction counts
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nm2 = {neg_m, neg_m};
+        f32x2 ps2 = {0.f, 0.f};
         f16x8 pb[KV / 32][2];
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pe = __builtin_amdgcn_exp2f(fmaf(st[kt][r], p.scale_log2, neg_m));
-                psum += pe;
-                pb[kt][r >> 3][r & 7] = (f16)pe;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = {st[kt][r], st[kt][r + 1]};
+                v = __builtin_elementwise_fma(v, sc2, nm2);
+                f32x2 e;
+                e.x = __builtin_amdgcn_exp2f(v.x);
+                e.y = __builtin_amdgcn_exp2f(v.y);
+                ps2 += e;
+                pb[kt][r >> 3][r & 7] = (f16)e.x;
+                pb[kt][r >> 3][(r & 7) + 1] = (f16)e.y;
             }
-        l_run += psum;
+        l_run += ps2.x + ps2.y;
 
         // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3)
 #pragma unroll
@@ -218,14 +266,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 for (int i = 0; i < DB; ++i) {
                     const f16* vr = Vt + (i * 32 + l31) * VROW + kb;
                     U2H4 lo, hi4;
-                    lo.u = *reinterpret_cast<const uint2*>(vr);
-                    hi4.u = *reinterpret_cast<const uint2*>(vr + 8);
+                    if constexpr (PREFETCH_V) {
+                        lo.u = vfrag[kt][s][i][0];
+                        hi4.u = vfrag[kt][s][i][1];
+                    } else {
+                        lo.u = *reinterpret_cast<const uint2*>(vr);
+                        hi4.u = *reinterpret_cast<const uint2*>(vr + 8);
+                    }
                     f16x8 a;
                     a[0] = lo.e[0]; a[1] = lo.e[1]; a[2] = lo.e[2]; a[3] = lo.e[3];
                     a[4] = hi4.e[0]; a[5] = hi4.e[1]; a[6] = hi4.e[2]; a[7] = hi4.e[3];
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kt][s], acc[i], 0, 0, 0);
                 }
             }
+        // stage the next tile: into the other buffer (one barrier per tile) or, single-buffered, after everyone is done
+        if (NBUF == 1) __syncthreads();
+        if (t + 1 < ntiles) store_kv((NBUF == 2) ? ((t + 1) & 1) : 0);
+        __syncthreads();
     }
 
     // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query

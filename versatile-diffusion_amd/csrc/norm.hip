@@ -1,8 +1,8 @@
 // GroupNorm(+SiLU) and LayerNorm for channels-last fp16 activations (gfx950).
 // HBM-bound: every element is read with 16-byte loads, statistics in fp32.
 //
-// GroupNorm runs as three launches: per-slab partial sums -> finalize (mean, rstd per (b, group))
-// -> normalise * gamma + beta (+SiLU).  The input may be the channel-concatenation of two tensors
+// GroupNorm runs as two launches: per-slab partial sums -> [fold partials to mean/rstd per (b, group), then]
+// normalise * gamma + beta (+SiLU).  The input may be the channel-concatenation of two tensors
 // (skip connections of the UNet up path), which is read in place.
 // Reference: GroupNorm32/normalization (lib/model_zoo/diffusion_utils.py:175-191), SiLU in
 // ResBlock.in_layers/out_layers (openaimodel.py:196-200,230-237), Normalize eps=1e-6
@@ -90,38 +90,37 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
     if (tid < groups * 2) part[((size_t)b * g.nchunk + chunk) * groups * 2 + tid] = ls[tid];
 }
 
-// one block per batch element: mean / rstd per group
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, float* stat, int nchunk, int groups,
-                                                          float inv_count, float eps) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    __shared__ float ls[256];
-    // thread t accumulates entry (t % (2*groups)) over chunks t/(2*groups), stride 256/(2*groups)
-    const int ne = groups * 2;
-    const int e = tid % ne, lanes = 256 / ne, cl = tid / ne;
-    float acc = 0.f;
-    if (cl < lanes)
-        for (int c = cl; c < nchunk; c += lanes) acc += part[((size_t)b * nchunk + c) * ne + e];
-    ls[tid] = (cl < lanes) ? acc : 0.f;
-    __syncthreads();
-    if (tid < ne) {
-        float t = 0.f;
-        for (int l = 0; l < lanes; ++l) t += ls[l * ne + tid];
-        ls[tid] = t;
-    }
-    __syncthreads();
-    if (tid < groups) {
-        const float mean = ls[tid * 2] * inv_count;
-        float var = ls[tid * 2 + 1] * inv_count - mean * mean;
-        if (var < 0.f) var = 0.f;
-        stat[((size_t)b * groups + tid) * 2] = mean;
-        stat[((size_t)b * groups + tid) * 2 + 1] = rsqrtf(var + eps);
-    }
-}
-
+// normalise * gamma + beta (+SiLU).  Every block first folds the slab partial sums of its batch element into
+// mean / rstd per group (<= 256 slabs x 64 values, L2-resident) -- cheaper than a separate finalize launch.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
-                                                       const f16* beta, const float* stat, f16* y, int HW, int groups,
-                                                       int apply_silu, GnGeom g) {
+                                                       const f16* beta, const float* part, f16* y, int HW, int groups,
+                                                       int apply_silu, float inv_count, float eps, GnGeom g) {
     const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    __shared__ float red[256];
+    __shared__ float stat[64 * 2];
+    {
+        const int ne = groups * 2;
+        const int e = tid % ne, lanes = 256 / ne, cl = tid / ne;
+        float acc = 0.f;
+        if (cl < lanes)
+            for (int c = cl; c < g.nchunk; c += lanes) acc += part[((size_t)b * g.nchunk + c) * ne + e];
+        red[tid] = (cl < lanes) ? acc : 0.f;
+        __syncthreads();
+        if (tid < ne) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += red[l * ne + tid];
+            red[tid] = t;
+        }
+        __syncthreads();
+        if (tid < groups) {
+            const float mean = red[tid * 2] * inv_count;
+            float var = red[tid * 2 + 1] * inv_count - mean * mean;
+            if (var < 0.f) var = 0.f;
+            stat[tid * 2] = mean;
+            stat[tid * 2 + 1] = rsqrtf(var + eps);
+        }
+        __syncthreads();
+    }
     const int cg = g.C / groups;
     const int tc = tid % g.TC, rl = tid / g.TC;
     if (rl >= g.R) return;
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int gi = (cc * 8 + i) / cg;
-                const float mean = stat[((size_t)b * groups + gi) * 2];
-                const float rstd = stat[((size_t)b * groups + gi) * 2 + 1];
+                const float mean = stat[gi * 2];
+                const float rstd = stat[gi * 2 + 1];
                 sc[pos][i] = rstd * (float)ga.e[i];
                 sh[pos][i] = (float)be.e[i] - mean * sc[pos][i];
             }
@@ -239,13 +238,11 @@ extern "C" int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int
     VD_REQUIRE(C <= GN_MAX_POS * 256 * 8, "vd_groupnorm_silu_f16: C=%d too large", C);
     const GnGeom g = gn_geom(HW, C);
     float* part = stats;
-    float* stat = stats + (size_t)B * g.nchunk * groups * 2;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1,
                        c1, part, HW, groups, g);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part, stat, g.nchunk, groups,
-                       1.0f / ((float)HW * (float)(C / groups)), eps);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1, c1,
-                       (const f16*)gamma, (const f16*)beta, stat, (f16*)y, HW, groups, apply_silu, g);
+                       (const f16*)gamma, (const f16*)beta, part, (f16*)y, HW, groups, apply_silu,
+                       1.0f / ((float)HW * (float)(C / groups)), eps, g);
     return vd_check_launch("vd_groupnorm_silu_f16");
 }
 
