@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int VD_GEMM_DEFAULT_DMA = 2;  // LDS-DMA, two stages (measured: +8..15 % over register staging; 3 stages lose occupancy)
+constexpr int VD_GEMM_DEFAULT_DEEP = 3;
 constexpr int BK = 64;           // K tile (halfs); one LDS row = 128 bytes = 8 x 16-byte slots
 constexpr int ROW_BYTES = BK * 2;
 
@@ -73,6 +74,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -831,6 +834,14 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
 #define VD_LAUNCH(BM_, BN_, WM_, WN_, NT_)                                                        \
     (dma == 2 ? launch_cfg<BM_, BN_, WM_, WN_, NT_, 2>(a, nsplit, stream)                         \
               : launch_cfg<BM_, BN_, WM_, WN_, NT_, 0>(a, nsplit, stream))
+    // grids that cannot fill the CUs twice over are latency-bound per block: give those a deeper DMA ring instead
+    const int grid_blocks = a.tiles_m * a.tiles_n * nsplit * zb;
+    static const char* deep_env = getenv("VD_GEMM_DEEP");
+    const int deep = deep_env ? (deep_env[0] - '0') : VD_GEMM_DEFAULT_DEEP;
+    if (dma == 2 && deep >= 3 && grid_blocks <= 400 && a.kt_per_split >= 8 && (cfg == T128x64 || cfg == T64x64)) {
+        if (cfg == T128x64) rc = deep == 4 ? launch_cfg<128, 64, 64, 32, 256, 4>(a, nsplit, stream) : launch_cfg<128, 64, 64, 32, 256, 3>(a, nsplit, stream);
+        else rc = deep == 4 ? launch_cfg<64, 64, 32, 32, 256, 4>(a, nsplit, stream) : launch_cfg<64, 64, 32, 32, 256, 3>(a, nsplit, stream);
+    } else
     switch (cfg) {
         case T128x128: rc = VD_LAUNCH(128, 128, 64, 64, 256); break;
         case T128x64: rc = VD_LAUNCH(128, 64, 64, 32, 256); break;
