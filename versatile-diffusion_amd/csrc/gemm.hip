@@ -838,7 +838,9 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int grid_blocks = a.tiles_m * a.tiles_n * nsplit * zb;
     static const char* deep_env = getenv("VD_GEMM_DEEP");
     const int deep = deep_env ? (deep_env[0] - '0') : VD_GEMM_DEFAULT_DEEP;
-    if (dma == 2 && deep >= 3 && grid_blocks <= 400 && a.kt_per_split >= 8 && (cfg == T128x64 || cfg == T64x64)) {
+    static const char* deep_blk_env = getenv("VD_GEMM_DEEP_MAXBLK");
+    const int deep_maxblk = deep_blk_env ? atoi(deep_blk_env) : 400;
+    if (dma == 2 && deep >= 3 && grid_blocks <= deep_maxblk && a.kt_per_split >= (deep_blk_env ? 3 : 8) && (cfg == T128x64 || cfg == T64x64)) {
         if (cfg == T128x64) rc = deep == 4 ? launch_cfg<128, 64, 64, 32, 256, 4>(a, nsplit, stream) : launch_cfg<128, 64, 64, 32, 256, 3>(a, nsplit, stream);
         else rc = deep == 4 ? launch_cfg<64, 64, 32, 32, 256, 4>(a, nsplit, stream) : launch_cfg<64, 64, 32, 32, 256, 3>(a, nsplit, stream);
     } else

@@ -102,8 +102,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
         const int ne = groups * 2;
         const int e = tid % ne, lanes = 256 / ne, cl = tid / ne;
         float acc = 0.f;
-        if (cl < lanes)
-            for (int c = cl; c < g.nchunk; c += lanes) acc += part[((size_t)b * g.nchunk + c) * ne + e];
+        if (cl < lanes) {
+            const float* pp = part + (size_t)b * g.nchunk * ne + e;
+            int c = cl;
+            for (; c + 7 * lanes < g.nchunk; c += 8 * lanes) {  // 8 independent loads in flight: this is a latency chain
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = pp[(size_t)(c + u * lanes) * ne];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += t[u];
+            }
+            for (; c < g.nchunk; c += lanes) acc += pp[(size_t)c * ne];
+        }
         red[tid] = (cl < lanes) ? acc : 0.f;
         __syncthreads();
         if (tid < ne) {
