@@ -98,8 +98,21 @@ def roofline_leg(net, batch, ctx, uctx, device):
     dom = max(table, key=lambda n: table[n]["ms"])
     d = table[dom]
     achieved = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 corrections
+    # applied) over tools/unet_forward.py -- PMC collection cannot run inside this process; null when not collected
+    traffic, traffic_note = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pt = json.load(f)
+        key = dom.replace(">", ",2>") if dom.count(",") == 4 else dom  # table names carry the DMA-stage template arg
+        ent = pt["kernels"].get(key)
+        if ent:
+            traffic, traffic_note = ent["hbm_side_bytes_per_launch"], "profiles/r01_pmc_traffic.json: " + pt["note"]
+    except Exception:
+        pass
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": traffic_note,
             "launches_per_forward": d["launches"], "avg_launch_us": round(d["avg_us"], 1),
             "algorithmic_gflop_per_launch": round(d["gflop"] / max(d["launches"], 1), 2),
             "forward_ms_instrumented": round(sum(v["ms"] for v in table.values()), 3)}

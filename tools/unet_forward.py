@@ -1,0 +1,17 @@
+"""N UNet forwards at the bench shape (CFG batch 8, 64x64 latent, L=77); target for rocprofv3 --pmc."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+os.environ.setdefault("VD_QUIET", "1")
+import torch
+import bench
+dev = torch.device("cuda:0")
+net = bench.build_model(dev)
+B = 4
+x = torch.randn(2 * B, 4, 64, 64, device=dev, dtype=torch.float16)
+t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+c = torch.randn(2 * B, 77, 768, device=dev, dtype=torch.float16) * 0.5
+ci = {"type": "text", "c": c, "kv_cache": {}}
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
+    net.apply_model({"type": "image", "x": x}, t, ci)
+torch.cuda.synchronize()

@@ -79,6 +79,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+__device__ __forceinline__ void vd_store16_nt(void* p, uint4 v) {
+#ifdef VD_NO_NT_STORE
+    *reinterpret_cast<uint4*>(p) = v;
+#else
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+#endif
+}
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -224,7 +233,9 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                     b.u = pre_rv[k];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + (float)b.e[i]);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col) = o.u;
+                    // streaming output: non-temporal so 20..80 MB of results do not evict the weight / activation panels
+                    // that the other tiles of this XCD keep re-reading from its 4 MiB L2
+                    vd_store16_nt(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col, o.u);
                 } else {
                     float v[8];
 #pragma unroll
