@@ -168,6 +168,10 @@ const char* vd_last_error(void);
 int vd_abi_version(void);
 /* writes lane->(row,col) maps of the 32x32x16 f16 MFMA as observed on the device; used by tests */
 int vd_probe_mfma_layout(int32_t* out_a_k, int32_t* out_c_row, int32_t* out_c_col, hipStream_t stream);
+/* ds_read_b64_tr_b16 as observed on the device: LDS holds lds[i] = i (4096 int16); lane l reads at byte address
+ * addr_bytes[l] (64 entries) and out[l*4 + j] receives its four 16-bit results; used by tests (the attention kernel's
+ * V operand relies on this gather) */
+int vd_probe_lds_tr16(const int32_t* addr_bytes, int16_t* out, hipStream_t stream);
 
 #ifdef __cplusplus
 }

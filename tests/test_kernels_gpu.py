@@ -41,6 +41,20 @@ def test_mfma_layout_probe(ops, dev):
     assert a_k.tolist() == list(range(16)), "A/B k-slot pairing is not the identity: %s" % a_k.tolist()
 
 
+def test_lds_transpose_read_probe(ops, dev):
+    """ds_read_b64_tr_b16 semantics the attention kernel's V operand is built on: in every 16-lane group, lane i supplies
+    the address of 4 contiguous halfs = row (i>>2), column quad (i&3) of a [4][16] block (row stride free), and receives
+    column i of that block (4 rows)."""
+    stride = 64  # bytes between block rows (the V panels use 64-byte rows)
+    lanes = torch.arange(64)
+    g, i = lanes >> 4, lanes & 15
+    addr = (g * 1024 + (i >> 2) * stride + (i & 3) * 8).to(torch.int32).to(dev)
+    got = ops.probe_lds_tr16(addr).long()
+    j = torch.arange(4).view(1, 4)
+    exp = (g.view(64, 1) * 1024 + j * stride) // 2 + i.view(64, 1)   # element index of block[j][i]
+    assert torch.equal(got, exp), "transpose-read gather differs:\n%s\nexpected\n%s" % (got[:20], exp[:20])
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 192, 128), (77, 768, 768), (4096, 64, 2560),
                                    (33, 8, 64), (512, 1280, 1280), (130, 4, 320), (100, 72, 16), (256, 128, 200)])
 def test_gemm_plain(ops, dev, M, N, K):

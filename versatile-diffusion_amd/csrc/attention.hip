@@ -14,6 +14,7 @@
 //   transposed while it is staged (LDS holds V^T[d][key]) so the A operand is two ds_read_b64.
 //   O^T accumulators: lane owns its query column again, so rescaling by exp(m_old - m_new) is
 //   lane-local as well.
+#include <type_traits>
 #include "vd_common.h"
 #include "../../include/vd_hip.h"
 
@@ -24,7 +25,6 @@ namespace {
 #endif
 constexpr int KV = 64;    // keys per tile
 constexpr int QB = 128;   // queries per block (4 waves x 32)
-constexpr int VROW = KV + 4;  // V^T row stride in halfs: 136 bytes -> conflict-free ds_read_b64
 constexpr float RESCALE_THR = 6.0f;  // log2 units: P values stay <= 64 between rescales
 
 struct AttnArgs {
@@ -42,21 +42,20 @@ struct AttnArgs {
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int KS = (D + 15) / 16;       // k-steps of the QK^T MFMA
-    constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T
-    constexpr int KROW = KS * 16 + 8;       // K row stride in halfs (odd number of 16-byte slots)
-    constexpr int KCH = KS * 2;             // 16-byte chunks per staged K row (zero padded past D)
-    constexpr int VCH = D / 8;              // 16-byte chunks per V row
-    constexpr int K_ITERS = (KV * KCH + 255) / 256;
-    constexpr int VITEMS = (KV / 2) * VCH;  // one item = 2 adjacent keys x 8 channels -> 8 dword LDS writes
-    constexpr int V_ITERS = (VITEMS + 255) / 256;
+    constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T == 32-column panels of the V image
+    constexpr int CPR = 2 * KS + 1;         // 16-byte chunks per K row in LDS: data, zero pad to KS*16, +1 (odd stride)
+    constexpr int KROW = CPR * 8;           // K row stride in halfs
+    constexpr int K_BYTES = KV * CPR * 16;  // K image: [64 keys][CPR chunks]
+    constexpr int V_BYTES = DB * KV * 64;   // V image: DB panels of [64 keys][32 halfs] (64-byte rows)
+    constexpr int TILE_BYTES = K_BYTES + V_BYTES;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
-    // double-buffered K / V^T tiles (one barrier per tile) where two copies fit the 64 KiB static LDS limit
-    constexpr int TILE_HALFS = KV * KROW + DB * 32 * VROW;
-    constexpr int NBUF = (2 * TILE_HALFS * 2 <= 60 * 1024) ? 2 : 1;
+    // double-buffered tiles (one barrier per tile) where two copies fit the 64 KiB static LDS limit
+    constexpr int NBUF = (2 * TILE_BYTES <= 60 * 1024) ? 2 : 1;
 
-    __shared__ __attribute__((aligned(16))) f16 lds_all[NBUF * TILE_HALFS];
+    __shared__ __attribute__((aligned(1024))) char lds_all[NBUF * TILE_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
 
     // XCD-aware mapping: keep all query blocks of one (batch, head) on one XCD so K/V stay in its L2
@@ -78,8 +77,42 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     const f16* vp = p.v + (size_t)b * p.sv + h * D;
     f16* op = p.o + (size_t)b * p.so + h * D;
 
-    // zero the tiles once (V^T rows d >= D must be finite)
-    for (int i = tid; i < NBUF * TILE_HALFS / 2; i += 256) reinterpret_cast<uint32_t*>(lds_all)[i] = 0u;
+    // ---- staging plan.  K and V tiles go global -> LDS by DMA (buffer_load ... lds): no VGPR round trip, no ds_write,
+    // no transpose pass.  A DMA instruction writes lane * 16 bytes linearly, so the LDS image is chosen by WHICH 16 bytes
+    // each lane fetches:
+    //   K image  [key][CPR chunks]         chunk q -> key q / CPR, slot q % CPR (slots past D fetch out of range = zeros)
+    //   V image  [panel][key][32 halfs]    chunk q -> panel q >> 8, key (q >> 2) & 63, 8 channels (q & 3) of the panel
+    // Rows past Nk fall outside the buffer descriptor and read as zeros (the tile offset lives in the VGPR offset: the
+    // SGPR offset is not range checked).  V stays row-major; ds_read_b64_tr_b16 transposes it on the way to the MFMA.
+    const i32x4 rs_k = make_rsrc_words(kp, (unsigned)(((size_t)(p.Nk - 1) * p.ldk + D) * 2));
+    const i32x4 rs_v = make_rsrc_words(vp, (unsigned)(((size_t)(p.Nk - 1) * p.ldv + D) * 2));
+    constexpr unsigned OOB = 0x80000000u;
+    // wave w issues K instructions w, w+4, ... (< CPR) and V instructions w, w+4, ... (4*DB of them: DB per wave)
+    constexpr int KM = (CPR + 3) / 4;
+    unsigned voff_k[KM], voff_v[DB];
+#pragma unroll
+    for (int m = 0; m < KM; ++m) {
+        const int q = (wave + 4 * m) * 64 + lane;
+        const int r = q / CPR, slot = q - r * CPR;
+        voff_k[m] = (slot * 8 < D) ? (unsigned)((r * p.ldk + slot * 8) * 2) : OOB;
+    }
+#pragma unroll
+    for (int m = 0; m < DB; ++m) {
+        const int q = (wave + 4 * m) * 64 + lane;
+        const int d0 = (q >> 8) * 32 + (q & 3) * 8;
+        voff_v[m] = (d0 < D) ? (unsigned)((((q >> 2) & 63) * p.ldv + d0) * 2) : OOB;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_all;
+    const unsigned k_tile_stride = (unsigned)(KV * p.ldk * 2), v_tile_stride = (unsigned)(KV * p.ldv * 2);
+    auto stage = [&](int t, int buf) {
+        const unsigned dst = lds0 + (unsigned)(buf * TILE_BYTES) + (unsigned)(wave * 1024);
+        const unsigned kt_off = (unsigned)t * k_tile_stride, vt_off = (unsigned)t * v_tile_stride;
+#pragma unroll
+        for (int m = 0; m < KM; ++m)
+            if (m < CPR / 4 || wave < CPR % 4) dma16(rs_k, dst + m * 4096, voff_k[m] + kt_off, 0);
+#pragma unroll
+        for (int m = 0; m < DB; ++m) dma16(rs_v, dst + K_BYTES + m * 4096, voff_v[m] + vt_off, 0);
+    };
 
     // ---- Q fragments: B operand, lane = (query l31, k-half hi), 8 consecutive d per k-step
     const int qrow = qb * QB + wave * 32 + l31;
@@ -106,70 +139,31 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         ntiles = min(ntiles, last_q / KV + 1);
     }
 
-    uint4 rk[K_ITERS], rv[V_ITERS][2];
-    auto load_kv = [&](int t) {
-        const int key0 = t * KV;
-#pragma unroll
-        for (int it = 0; it < K_ITERS; ++it) {
-            const int c = tid + it * 256;
-            const int r = c / KCH, ch = c - r * KCH;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < KV * KCH && key0 + r < p.Nk && ch * 8 < D)
-                v = *reinterpret_cast<const uint4*>(kp + (size_t)(key0 + r) * p.ldk + ch * 8);
-            rk[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < V_ITERS; ++it) {
-            const int c = tid + it * 256;
-            const int kpair = c % (KV / 2), ch = c / (KV / 2);  // key pair fastest: conflict-free transposed writes
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int key = key0 + 2 * kpair + h2;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < VITEMS && key < p.Nk) v = *reinterpret_cast<const uint4*>(vp + (size_t)key * p.ldv + ch * 8);
-                rv[it][h2] = v;
-            }
-        }
-    };
-    auto store_kv = [&](int buf) {
-        f16* Ks = lds_all + buf * TILE_HALFS;
-        f16* Vt = Ks + KV * KROW;
-#pragma unroll
-        for (int it = 0; it < K_ITERS; ++it) {
-            const int c = tid + it * 256;
-            const int r = c / KCH, ch = c - r * KCH;
-            if (c < KV * KCH) *reinterpret_cast<uint4*>(Ks + r * KROW + ch * 8) = rk[it];
-        }
-#pragma unroll
-        for (int it = 0; it < V_ITERS; ++it) {
-            const int c = tid + it * 256;
-            const int kpair = c % (KV / 2), ch = c / (KV / 2);
-            if (c < VITEMS) {
-                U4H8 a, b;
-                a.u = rv[it][0];
-                b.u = rv[it][1];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {  // V^T[d][2*kpair .. +1] as one dword: lanes -> consecutive banks
-                    f16x2 pr;
-                    pr[0] = a.e[i];
-                    pr[1] = b.e[i];
-                    *reinterpret_cast<f16x2*>(Vt + (ch * 8 + i) * VROW + 2 * kpair) = pr;
-                }
-            }
-        }
-    };
+    // per-lane LDS byte offsets of the operand reads inside a tile
+    const unsigned k_lane = (unsigned)((l31 * KROW + hi * 8) * 2);
+    // transpose read: in each 16-lane group lane i addresses row (i >> 2), column quad (i & 3) of a [4 keys][16 d] block
+    // and receives column i; groups = (d half of the panel, key half hi)
+    const unsigned v_lane = (unsigned)(K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_h4_ptr;
 
-    if (ntiles > 0) {
-        load_kv(0);
-        __syncthreads();  // orders the zero fill
-        store_kv(0);
-    }
+    stage(0, 0);
+    // The Q loads are the only VMEM results the compiler tracks: consume them here so its s_waitcnt vmcnt(0) lands before
+    // the loop.  (It cannot see the hand-written waits; left pending, it would drain vmcnt -- and with it the DMA just
+    // issued for the next tile -- in front of the first MFMA of every iteration.)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+    wait_vmcnt<0>();
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+
+    // One K/V tile.  HAS_NEXT is a compile-time flag: the steady-state iterations fetch tile t+1 unconditionally and the
+    // last tile is peeled.
+    auto tile = [&](const int t, auto has_next) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int cur = (NBUF == 2) ? (t & 1) : 0;
-        const f16* Ks = lds_all + cur * TILE_HALFS;
-        const f16* Vt = Ks + KV * KROW;
-        if (t + 1 < ntiles) load_kv(t + 1);  // in flight under the MFMAs below
+        const unsigned tbase = lds0 + (unsigned)(cur * TILE_BYTES);
+        const f16* Ks = reinterpret_cast<const f16*>(lds_all + cur * TILE_BYTES);
+        if constexpr (HAS_NEXT && NBUF == 2) stage(t + 1, cur ^ 1);  // lands while this tile is being consumed
 
         // ---- S^T tiles (keys x queries)
         f32x16 st[KV / 32];
@@ -183,23 +177,6 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
                 // first k-step takes C = 0 as an inline constant: no 16-register zero fill per tile
                 st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? zero16 : st[kt], 0, 0, 0);
             }
-        }
-
-        // V^T fragments of this tile are requested BEFORE the softmax math so the LDS latency hides under the VALU
-        // work instead of stalling each P.V MFMA (affordable for head dims <= 96: 16 / 24 fragment registers pairs)
-        constexpr bool PREFETCH_V = false;  // measured: +14 VGPRs drop 3 -> 2 waves/SIMD and cost 13 %; occupancy wins
-        uint2 vfrag[PREFETCH_V ? KV / 32 : 1][2][PREFETCH_V ? DB : 1][2];
-        if constexpr (PREFETCH_V) {
-#pragma unroll
-            for (int kt = 0; kt < KV / 32; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int i = 0; i < DB; ++i) {
-                        const f16* vr = Vt + (i * 32 + l31) * VROW + kt * 32 + 16 * s2 + 4 * hi;
-                        vfrag[kt][s2][i][0] = *reinterpret_cast<const uint2*>(vr);
-                        vfrag[kt][s2][i][1] = *reinterpret_cast<const uint2*>(vr + 8);
-                    }
         }
 
         // ---- online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
@@ -235,8 +212,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
             m_run = m_new;
         }
         const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
-        // the softmax body is VALU-issue bound (3 waves per SIMD share one VALU port): packed fp32 math for the
-        // scale/shift and the row sum halves those instruction counts
+        // the softmax body is VALU-issue bound: packed fp32 math for the scale/shift and the row sum halves those
+        // instruction counts
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nm2 = {neg_m, neg_m};
         f32x2 ps2 = {0.f, 0.f};
@@ -256,34 +233,34 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
             }
         l_run += ps2.x + ps2.y;
 
-        // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3)
+        const lds_h4_ptr vbase = (lds_h4_ptr)(size_t)(tbase + v_lane);
+        // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3):
+        // the A operand is two transpose reads (keys +0..3 and +8..11 of this lane's key half) of row-major V
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int kb = kt * 32 + 16 * s + 4 * hi;
 #pragma unroll
                 for (int i = 0; i < DB; ++i) {
-                    const f16* vr = Vt + (i * 32 + l31) * VROW + kb;
-                    U2H4 lo, hi4;
-                    if constexpr (PREFETCH_V) {
-                        lo.u = vfrag[kt][s][i][0];
-                        hi4.u = vfrag[kt][s][i][1];
-                    } else {
-                        lo.u = *reinterpret_cast<const uint2*>(vr);
-                        hi4.u = *reinterpret_cast<const uint2*>(vr + 8);
-                    }
-                    f16x8 a;
-                    a[0] = lo.e[0]; a[1] = lo.e[1]; a[2] = lo.e[2]; a[3] = lo.e[3];
-                    a[4] = hi4.e[0]; a[5] = hi4.e[1]; a[6] = hi4.e[2]; a[7] = hi4.e[3];
+                    // one base VGPR per tile + immediate offsets (s16x4 units: 8 bytes)
+                    const int off8 = (i * KV * 64 + (kt * 32 + 16 * s) * 64) / 8;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vbase + off8);
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vbase + off8 + 64);
+                    const f16x8 a = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kt][s], acc[i], 0, 0, 0);
                 }
             }
-        // stage the next tile: into the other buffer (one barrier per tile) or, single-buffered, after everyone is done
-        if (NBUF == 1) __syncthreads();
-        if (t + 1 < ntiles) store_kv((NBUF == 2) ? ((t + 1) & 1) : 0);
-        __syncthreads();
-    }
+        if constexpr (HAS_NEXT) {
+            if constexpr (NBUF == 1) {  // single buffer: refill only after every wave is done with the tile
+                __syncthreads();
+                stage(t + 1, 0);
+            }
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile(t, std::true_type{});
+    tile(ntiles - 1, std::false_type{});
 
     // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -341,6 +318,8 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     VD_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "vd_attention_f16: empty problem B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     VD_REQUIRE((ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 4 == 0),
                "vd_attention_f16: leading dimensions must keep 16-byte row alignment");
+    VD_REQUIRE(((int64_t)Nk + KV) * ldk * 2 < (int64_t)1 << 31 && ((int64_t)Nk + KV) * ldv * 2 < (int64_t)1 << 31,
+               "vd_attention_f16: one (batch, head) K/V slice must stay below 2 GiB (Nk=%d ldk=%d ldv=%d)", Nk, ldk, ldv);
     AttnArgs a;
     a.q = (const f16*)q; a.k = (const f16*)k; a.v = (const f16*)v; a.o = (f16*)out;
     a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;

@@ -275,6 +275,18 @@ __global__ __launch_bounds__(256) void scale_by_row_norm_kernel(f16* z, const f1
     }
 }
 
+// ---- LDS transpose-read probe: what ds_read_b64_tr_b16 returns for per-lane byte addresses ----
+__global__ void probe_tr16_kernel(const int32_t* addr_bytes, int16_t* out) {
+    __shared__ __attribute__((aligned(16))) short lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) short*)lds;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(base + (unsigned)addr_bytes[threadIdx.x]));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+
 // ---- MFMA layout probe: one wave, one-hot operands, reports what the hardware does ----
 __global__ void probe_mfma_kernel(int32_t* out_a_k, int32_t* out_c_row, int32_t* out_c_col) {
     const int lane = threadIdx.x;
@@ -428,6 +440,12 @@ extern "C" int vd_scale_by_row_norm_f16(void* z, const void* ref, const int32_t*
     hipLaunchKernelGGL(scale_by_row_norm_kernel, dim3(B), dim3(256), 0, stream, (f16*)z, (const f16*)ref, pool_idx,
                        row_scale, L, C);
     return vd_check_launch("vd_scale_by_row_norm_f16");
+}
+
+extern "C" int vd_probe_lds_tr16(const int32_t* addr_bytes, int16_t* out, hipStream_t stream) {
+    VD_REQUIRE(addr_bytes && out, "vd_probe_lds_tr16: null pointer");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, addr_bytes, out);
+    return vd_check_launch("vd_probe_lds_tr16");
 }
 
 extern "C" int vd_probe_mfma_layout(int32_t* out_a_k, int32_t* out_c_row, int32_t* out_c_col, hipStream_t stream) {

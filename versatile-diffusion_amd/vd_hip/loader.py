@@ -3,7 +3,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-_LIB_PATH = os.path.join(_PKG, "libvd_hip.so")
+# VD_HIP_LIB: development override (kernel A/B experiments with variant builds of the same ABI)
+_LIB_PATH = os.environ.get("VD_HIP_LIB") or os.path.join(_PKG, "libvd_hip.so")
 _lib = None
 
 
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "vd_last_error": (ctypes.c_char_p, []),
     "vd_abi_version": (_I, []),
     "vd_probe_mfma_layout": (_I, [_P, _P, _P, _P]),
+    "vd_probe_lds_tr16": (_I, [_P, _P, _P]),
 }
 
 

@@ -375,6 +375,14 @@ def scale_by_row_norm_(z, *, ref=None, pool_idx=None, row_scale=None):
     return z
 
 
+def probe_lds_tr16(addr_bytes):
+    """addr_bytes: (64,) int32 per-lane LDS byte addresses -> (64, 4) int16 values read by ds_read_b64_tr_b16."""
+    _req(addr_bytes, "addr_bytes", torch.int32)
+    out = torch.zeros((64, 4), dtype=torch.int16, device=addr_bytes.device)
+    _check(lib().vd_probe_lds_tr16(_ptr(addr_bytes), _ptr(out), _stream()))
+    return out.cpu()
+
+
 def probe_mfma_layout(device):
     a_k = torch.full((16,), -2, dtype=torch.int32, device=device)
     c_row = torch.zeros((64, 16), dtype=torch.int32, device=device)
