@@ -15,3 +15,12 @@ ci = {"type": "text", "c": c, "kv_cache": {}}
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     net.apply_model({"type": "image", "x": x}, t, ci)
 torch.cuda.synchronize()
+if len(sys.argv) > 2 and sys.argv[2] == "time":
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            net.apply_model({"type": "image", "x": x}, t, ci)
+        e1.record()
+        torch.cuda.synchronize()
+        print("forward ms: %.3f" % (e0.elapsed_time(e1) / 10))

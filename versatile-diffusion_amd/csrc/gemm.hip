@@ -669,8 +669,12 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            vd_set_error("vd_gemm_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+            return VD_ERR_LAUNCH;
+        }
         attr_done = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
@@ -741,37 +745,68 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         a.plain = (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.ups == 0 && d.Hin * d.Win == d.Hout * d.Wout) ? 1 : 0;
     }
 
-    // ---- tile / split heuristic.  Bigger tiles halve the L2->LDS traffic per FLOP; the grid should still hold
-    // >= ~2 blocks per CU (512), which small-M / deep-K problems reach through split-K (fp32 slabs + reduce).
-    TileCfg cfg;
-    auto tiles = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+    // ---- tile / split choice: a small cost model, calibrated on MI355X with tools/gemm_sweep.py.
+    // A launch runs in "rounds" of `cap` co-resident blocks (LDS / VGPR limits per CU x 256 CUs); the time of one
+    // 64-deep K tile of one block depends on how full the CUs are (t_solo: <= 1 block per CU .. t_full: every slot
+    // taken; the chip also clocks higher when part of it idles).  Split-K adds the fp32 slab round trip + one reduce
+    // launch.  What this buys over fixed thresholds: grids that just overflow a round (e.g. 640 blocks on 512 slots
+    // ran 2 rounds at 25 % more time than 480 blocks in one) are avoided.
+    struct Cand { TileCfg cfg; int bm, bn, cap; float t_solo, t_full, lo, hi, fix; };
+    static const Cand cands[3] = {
+        {T128x128, 128, 128, 512, 0.75f, 1.10f, 0.50f, 1.00f, 5.f},
+        {T128x64, 128, 64, 768, 0.47f, 1.00f, 0.33f, 0.83f, 4.f},
+        {T64x64, 64, 64, 1024, 0.38f, 0.89f, 0.25f, 0.75f, 3.f}};
     const int zb = d.batch;
     const bool can_split = (d.ws != nullptr || d.split_k > 1) && d.act != VD_ACT_GEGLU && !(d.flags & VD_EPI_OUT_F32);
+    auto model_us = [&](const Cand& c, int ns) {
+        const int tiles = ((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * zb;
+        const long blocks = (long)tiles * ns;
+        const int kt = (a.kt_total + ns - 1) / ns;
+        const long full = blocks / c.cap, rem = blocks % c.cap;
+        float t = (float)full * (kt * c.t_full + c.fix);
+        if (rem) {
+            const float load = (float)rem / c.cap;
+            const float f = load <= c.lo ? 0.f : (load >= c.hi ? 1.f : (load - c.lo) / (c.hi - c.lo));
+            t += kt * (c.t_solo + f * (c.t_full - c.t_solo)) + c.fix;
+        }
+        if (ns > 1) t += 3.f + 2.f * ns * (float)d.M * d.N * zb * 4.f / 8.0e6f + 2.f;  // slabs at ~8 TB/s (cache resident) + launch
+        return t;
+    };
+    TileCfg cfg = T64x64;
+    int nsplit = 1;
     if (d.act == VD_ACT_GEGLU) cfg = T128x128w8;  // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others
     else if (d.M < 96 || d.N < 96) cfg = T64x64;
-    else if (d.N % 128 == 0 && (tiles(128, 128) * zb >= 448 || (can_split && a.kt_total >= 64))) cfg = T128x128;
-    else if (tiles(128, 64) * zb >= 320 || (can_split && a.kt_total >= 64)) cfg = T128x64;
-    else cfg = T64x64;
+    else {
+        float best = 1e30f;
+        const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1);
+        for (const Cand& c : cands)
+            for (int ns = (d.split_k > 0 ? d.split_k : 1); ns <= ns_max; ++ns) {
+                if (ns > 1 && a.kt_total / ns < 8) break;
+                const float t = model_us(c, ns);
+                if (t < best) { best = t; cfg = c.cfg; nsplit = ns; }
+            }
+    }
     {   // developer override for tile experiments: VD_GEMM_TILE=0|1|2 (never set in production runs)
         static const char* ov = getenv("VD_GEMM_TILE");
-        if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3')) cfg = (TileCfg)(ov[0] - '0');
+        if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3')) {
+            cfg = (TileCfg)(ov[0] - '0');
+            if (d.split_k <= 0 && cfg <= T64x64) {  // re-plan the split for the forced tile
+                float best = 1e30f;
+                const int ns_max = (can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1;
+                for (int ns = 1; ns <= ns_max; ++ns) {
+                    if (ns > 1 && a.kt_total / ns < 8) break;
+                    const float t = model_us(cands[(int)cfg], ns);
+                    if (t < best) { best = t; nsplit = ns; }
+                }
+            }
+        }
     }
+    if (d.split_k > 0) nsplit = d.split_k;
     int bm = 128, bn = 128;
     if (cfg == T128x64 || cfg == T128x64w8) { bm = 128; bn = 64; }
     if (cfg == T64x64) { bm = 64; bn = 64; }
     a.tiles_m = (d.M + bm - 1) / bm;
     a.tiles_n = (d.N + bn - 1) / bn;
-
-    int nsplit = 1;
-    if (d.split_k > 0) nsplit = d.split_k;
-    else if (can_split) {
-        const int nblk = a.tiles_m * a.tiles_n * zb;
-        if (nblk < 384 && a.kt_total >= 32) {  // below K = 2048 the slab round trip + reduce launch costs more than it buys
-            nsplit = (640 + nblk - 1) / nblk;
-            if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
-            while (nsplit > 1 && a.kt_total / nsplit < 12) --nsplit;
-        }
-    }
     if (nsplit > a.kt_total) nsplit = a.kt_total;
     if (nsplit > 1) {
         VD_REQUIRE(d.ws != nullptr, "vd_gemm_f16: split_k=%d needs a workspace", nsplit);
