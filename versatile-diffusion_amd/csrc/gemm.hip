@@ -645,17 +645,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float* w = d.ws + (((size_t)z * nsplit + s) * d.M + row) * (size_t)d.N + col;
-            if (col + 8 <= d.N && (d.N & 3) == 0) {
+        const size_t slab = (size_t)d.M * d.N;
+        const float* w0 = d.ws + ((size_t)z * nsplit * d.M + row) * (size_t)d.N + col;
+        if (col + 8 <= d.N && (d.N & 3) == 0) {
+            int s = 0;
+            for (; s + 4 <= nsplit; s += 4) {  // 8 independent 16-byte loads in flight before the adds
+                float4 x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* w = w0 + (size_t)(s + u) * slab;
+                    x[u] = *reinterpret_cast<const float4*>(w);
+                    y[u] = *reinterpret_cast<const float4*>(w + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += x[u].x; v[1] += x[u].y; v[2] += x[u].z; v[3] += x[u].w;
+                    v[4] += y[u].x; v[5] += y[u].y; v[6] += y[u].z; v[7] += y[u].w;
+                }
+            }
+            for (; s < nsplit; ++s) {
+                const float* w = w0 + (size_t)s * slab;
                 const float4 x = *reinterpret_cast<const float4*>(w);
                 const float4 y = *reinterpret_cast<const float4*>(w + 4);
                 v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
                 v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
-            } else {
-                for (int i = 0; i < 8; ++i)
-                    if (col + i < d.N) v[i] += w[i];
             }
+        } else {
+            for (int s = 0; s < nsplit; ++s)
+                for (int i = 0; i < 8; ++i)
+                    if (col + i < d.N) v[i] += w0[(size_t)s * slab + i];
         }
         epi_store8(e, row, col, v);
     }

@@ -57,15 +57,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
             float s[8], q[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-            for (int r = r0 + rl; r < r1; r += g.R) {
-                U4H8 t;
-                t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + r, cc * 8));
+            // 4 rows per trip, all four 16-byte loads issued before any is consumed: with ~2 blocks per CU a single
+            // load in flight per thread left HBM at a quarter of its bandwidth (rows past the slab are clamped and
+            // weighted 0 rather than branched around, so the loads stay unconditional)
+            for (int r = r0 + rl; r < r1; r += 4 * g.R) {
+                U4H8 t[4];
+                float wgt[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float v = (float)t.e[i];
-                    s[i] += v;
-                    q[i] += v * v;
+                for (int u = 0; u < 4; ++u) {
+                    const int ru = r + u * g.R;
+                    wgt[u] = ru < r1 ? 1.f : 0.f;
+                    t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (ru < r1 ? ru : r), cc * 8));
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = (float)t[u].e[i] * wgt[u];
+                        s[i] += v;
+                        q[i] += v * v;
+                    }
             }
             // fold the (up to 8) channels into their groups, one LDS atomic per run
             int gcur = (cc * 8) / cg;
@@ -159,17 +170,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
     for (int pos = 0; pos < GN_MAX_POS; ++pos) {
         const int cc = tc + pos * g.TC;
         if (pos < g.npos && cc < g.C8) {
-            for (int r = r0 + rl; r < r1; r += g.R) {
-                const size_t row = (size_t)b * HW + r;
-                U4H8 t, o;
-                t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, row, cc * 8));
+            for (int r = r0 + rl; r < r1; r += 4 * g.R) {  // 4 loads in flight per thread, see gn_partial_kernel
+                U4H8 t[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float v = (float)t.e[i] * sc[pos][i] + sh[pos][i];
-                    if (apply_silu) v = vd_silu(v);
-                    o.e[i] = (f16)v;
+                for (int u = 0; u < 4; ++u) {
+                    const int ru = r + u * g.R;
+                    t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (ru < r1 ? ru : r), cc * 8));
                 }
-                *reinterpret_cast<uint4*>(y + row * g.C + cc * 8) = o.u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ru = r + u * g.R;
+                    U4H8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = (float)t[u].e[i] * sc[pos][i] + sh[pos][i];
+                        if (apply_silu) v = vd_silu(v);
+                        o.e[i] = (f16)v;
+                    }
+                    if (ru < r1) *reinterpret_cast<uint4*>(y + ((size_t)b * HW + ru) * g.C + cc * 8) = o.u;
+                }
             }
         }
     }
