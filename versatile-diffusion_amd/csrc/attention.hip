@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
     // double-buffered tiles (one barrier per tile) where two copies fit the 64 KiB static LDS limit
     constexpr int NBUF = (2 * TILE_BYTES <= 60 * 1024) ? 2 : 1;
+    constexpr bool HAS_ONES = (D % 32) != 0;  // spare rows in the last O^T block: row sums ride on the P.V MFMA (see below)
+    constexpr int ONES_COL = D % 32;          // column inside panel DB-1 (a multiple of 8: first half of a 16-byte chunk)
 
     __shared__ __attribute__((aligned(1024))) char lds_all[NBUF * TILE_BYTES];
 
@@ -114,6 +116,22 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         for (int m = 0; m < DB; ++m) dma16(rs_v, dst + K_BYTES + m * 4096, voff_v[m] + vt_off, 0);
     };
 
+    // lanes whose V chunk starts at column D of the last panel plant the 1.0 after their own DMA has landed
+    bool ones_lane[DB];
+#pragma unroll
+    for (int m = 0; m < DB; ++m) {
+        const int q = (wave + 4 * m) * 64 + lane;
+        ones_lane[m] = HAS_ONES && (q >> 8) == DB - 1 && (q & 3) == ONES_COL / 8;
+    }
+    auto plant_ones = [&](int buf) {
+        if constexpr (HAS_ONES) {
+#pragma unroll
+            for (int m = 0; m < DB; ++m)
+                if (ones_lane[m])
+                    *reinterpret_cast<f16*>(lds_all + buf * TILE_BYTES + K_BYTES + (wave + 4 * m) * 1024 + lane * 16) = (f16)1.0f;
+        }
+    };
+
     // ---- Q fragments: B operand, lane = (query l31, k-half hi), 8 consecutive d per k-step
     const int qrow = qb * QB + wave * 32 + l31;
     f16x8 qf[KS];
@@ -123,6 +141,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         U4H8 t;
         t.u = make_uint4(0, 0, 0, 0);
         if (qrow < p.Nq && d0 < D) t.u = *reinterpret_cast<const uint4*>(qp + (size_t)qrow * p.ldq + d0);
+        // softmax scale and log2(e) are folded into Q once: the scores leave the MFMA already in exp2 units
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.e[j] = (f16)((float)t.e[j] * p.scale_log2);
         qf[ks] = t.h;
     }
 
@@ -131,7 +152,16 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // Running max m of each query (log2 units) lives as -m in all 16 slots of `negm`, the C operand of the first QK^T MFMA:
+    // the matrix core subtracts it for free and S' = s - m comes out of the MFMA ready for exp2.  m lags behind the
+    // true row max by at most RESCALE_THR (deferred rescale), so P = exp2(S') <= 2^RESCALE_THR between rescales.
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    // Row sums: when the head dim leaves spare rows in the last 32-row block of O^T (D = 40, 80), V gets a column of
+    // ones at d = D, so the P.V MFMA accumulates sum_k P[k] in accumulator row D -- no VALU adds, and the deferred
+    // rescale covers it with the rest of the accumulator.
+    float l_run = 0.f;                // VALU row sum, only when !HAS_ONES
 
     int ntiles = (p.Nk + KV - 1) / KV;
     if (p.causal) {
@@ -154,6 +184,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
     wait_vmcnt<0>();
+    plant_ones(0);
     __syncthreads();
 
     // One K/V tile.  HAS_NEXT is a compile-time flag: the steady-state iterations fetch tile t+1 unconditionally and the
@@ -167,15 +198,13 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
 
         // ---- S^T tiles (keys x queries)
         f32x16 st[KV / 32];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 U4H8 a;
                 a.u = *reinterpret_cast<const uint4*>(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-                // first k-step takes C = 0 as an inline constant: no 16-register zero fill per tile
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? zero16 : st[kt], 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? negm : st[kt], 0, 0, 0);  // S' = s - m
             }
         }
 
@@ -197,41 +226,50 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[kt][r]), st[kt][r + 1]);  // v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float ms = mx * p.scale_log2;  // running max is tracked in scaled (log2) units
-        // Deferred rescale: the accumulators are only rescaled when some row's max grew by more than RESCALE_THR
-        // (then every lane updates exactly); otherwise P = exp2(s - m_old) <= 2^RESCALE_THR, harmless in fp16/fp32.
-        if (__any(ms > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, ms);
-            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // max of S' = how far this tile exceeds the running max
+        // Deferred rescale: accumulators and running max move only when some row grew by more than RESCALE_THR (then every
+        // lane updates exactly); otherwise P = exp2(S') <= 2^RESCALE_THR, harmless in fp16/fp32.  The first tile always
+        // takes this path (m starts at 0, the first row max may be far below it).
+        if (t == 0 || __any(mx > RESCALE_THR)) {
+            float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+            if (mx == -INFINITY) delta = 0.f;  // fully masked row so far: nothing to shift
+            if (t != 0) {  // nothing accumulated yet on the first tile
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                if constexpr (!HAS_ONES) l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < DB; ++i)
+                for (int i = 0; i < DB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
-            m_run = m_new;
-        }
-        const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
-        // the softmax body is VALU-issue bound: packed fp32 math for the scale/shift and the row sum halves those
-        // instruction counts
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nm2 = {neg_m, neg_m};
-        f32x2 ps2 = {0.f, 0.f};
-        f16x8 pb[KV / 32][2];
-#pragma unroll
-        for (int kt = 0; kt < KV / 32; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 v = {st[kt][r], st[kt][r + 1]};
-                v = __builtin_elementwise_fma(v, sc2, nm2);
-                f32x2 e;
-                e.x = __builtin_amdgcn_exp2f(v.x);
-                e.y = __builtin_amdgcn_exp2f(v.y);
-                ps2 += e;
-                pb[kt][r >> 3][r & 7] = (f16)e.x;
-                pb[kt][r >> 3][(r & 7) + 1] = (f16)e.y;
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
             }
-        l_run += ps2.x + ps2.y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+            for (int kt = 0; kt < KV / 32; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] -= delta;
+        }
+        f16x8 pb[KV / 32][2];
+        if constexpr (HAS_ONES) {
+#pragma unroll
+            for (int kt = 0; kt < KV / 32; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pb[kt][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(st[kt][r]);
+        } else {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KV / 32; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 e;
+                    e.x = __builtin_amdgcn_exp2f(st[kt][r]);
+                    e.y = __builtin_amdgcn_exp2f(st[kt][r + 1]);
+                    ps2 += e;
+                    pb[kt][r >> 3][r & 7] = (f16)e.x;
+                    pb[kt][r >> 3][(r & 7) + 1] = (f16)e.y;
+                }
+            l_run += ps2.x + ps2.y;
+        }
 
         const lds_h4_ptr vbase = (lds_h4_ptr)(size_t)(tbase + v_lane);
         // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3):
@@ -256,6 +294,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
                 stage(t + 1, 0);
             }
             wait_vmcnt<0>();
+            plant_ones((NBUF == 2) ? (cur ^ 1) : 0);
             __syncthreads();
         }
     };
@@ -263,7 +302,15 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     tile(ntiles - 1, std::false_type{});
 
     // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (HAS_ONES) {
+        // accumulator row D of the last block: local row D % 32 = (r & 3) + 8 * (r >> 2) with hi = 0 -> r = D % 32 / 2 (8 -> 4, 16 -> 8)
+        constexpr int RL = (ONES_COL & 3) + 4 * (ONES_COL >> 3);
+        static_assert(!HAS_ONES || (ONES_COL % 8 == 0 && ONES_COL < 32), "ones column must sit on a hi = 0 accumulator row");
+        l_tot = __shfl(acc[DB - 1][RL], l31, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
     if (qrow < p.Nq) {
 #pragma unroll
