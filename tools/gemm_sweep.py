@@ -18,8 +18,9 @@ SHAPES = [  # (B, H, W, Cin, Cout, ksize)
     (8, 16, 16, 640, 1280, 3), (8, 32, 32, 320, 640, 3),
     (8, 16, 16, 5120, 1280, 1), (8, 16, 16, 1280, 1280, 1), (8, 32, 32, 2560, 640, 1), (8, 64, 64, 1280, 320, 1),
     (8, 32, 32, 640, 640, 1), (8, 64, 64, 320, 320, 1), (8, 8, 8, 5120, 1280, 1),
+    (1, 64, 64, 4096, 4096, 1), (1, 64, 128, 8192, 8192, 1),
 ]
-SPLITS = [0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16]
+SPLITS = [int(v) for v in os.environ.get("VD_SWEEP_SPLITS", "0,1,2,3,4,5,6,8,10,12,16").split(",")]
 
 
 def timeit(fn, iters=30):

@@ -60,6 +60,15 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 
 // swizzled byte offset of (row r, 16-byte slot s) inside a [rows][64] f16 LDS tile
 __device__ __forceinline__ int lds_off(int r, int s) { return r * ROW_BYTES + ((s ^ ((r >> 1) & 7)) << 4); }
+// same idea for 32-deep K tiles (64-byte rows, 4 slots): rows r, r+4, r+8, r+12 of a ds_read_b128 lane group land on
+// the same 64-byte quarter of the 256-byte bank row and are spread over its 4 slots by (r >> 2) & 3
+template <int KB>
+__device__ __forceinline__ int lds_off_kb(int r, int s) {
+    if constexpr (KB == 64) return lds_off(r, s);
+    else return r * 64 + ((s ^ ((r >> 2) & 3)) << 4);
+}
+template <int KB>
+__device__ __forceinline__ int lds_swz(int r) { return KB == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
 struct EpiCtx {
     const f16* bias;
@@ -212,16 +221,20 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB = 64>
 __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const GemmArgs p) {
+    static_assert(KB == 64 || (KB == 32 && STAGES >= 2), "32-deep K tiles exist for the LDS-DMA ring only");
+    constexpr int KROW_BYTES = KB * 2;  // one LDS row of a stage
+    constexpr int SLOTS = KB / 8;       // 16-byte slots per row == threads cooperating on a row
+    constexpr int KSUB = 64 / KB;       // kernel K tiles per planner K tile (the planner counts in 64s)
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N * 64 == NT, "waves must tile the block");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int RPP = NT / 8;  // rows staged per pass: 8 threads per 128-byte row
+    constexpr int RPP = NT / SLOTS;  // rows staged per pass: SLOTS threads per row
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
     constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
-    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+    constexpr int STAGE_BYTES = (BM + BN) * KROW_BYTES;
     constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
 
     // per-thread gather coordinates: 8 threads per 128-byte row, RPP rows per pass
-    const int lrow = tid >> 3, lslot = tid & 7;
+    const int lrow = tid / SLOTS, lslot = tid % SLOTS;
     int a_iy0[A_PASSES], a_ix0[A_PASSES], a_pix[A_PASSES];
     const int HWo = d.Hout * d.Wout;
     const int Hv = d.Hin << d.ups, Wv = d.Win << d.ups;
@@ -288,10 +301,10 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
     }
 
     const int ctot = d.c0 + d.c1;
-    const int kt0 = split * p.kt_per_split;
-    int kt_end = kt0 + p.kt_per_split;
+    int kt_end = (split + 1) * p.kt_per_split;
     if (kt_end > p.kt_total) kt_end = p.kt_total;
-    const int nk = kt_end - kt0;
+    const int kt0 = split * p.kt_per_split * KSUB;  // in units of this kernel's K tile
+    const int nk = kt_end * KSUB - kt0;
     const bool ragged = (d.K % BK) != 0;
 
     // gather state of the current (tap, source) segment: per-pass byte offset of the pixel row, or OOB
@@ -353,27 +366,27 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int rd_a[BK / 16], rd_b[BK / 16];
+    int rd_a[KB / 16], rd_b[KB / 16];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-        rd_a[ks] = lds_off(wm * WM + l31, ks * 2 + hi);
-        rd_b[ks] = BM * ROW_BYTES + lds_off(wn * WN + l31, ks * 2 + hi);
+    for (int ks = 0; ks < KB / 16; ++ks) {
+        rd_a[ks] = lds_off_kb<KB>(wm * WM + l31, ks * 2 + hi);
+        rd_b[ks] = BM * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
     }
     auto compute_tile = [&](int buf) {
         const char* st = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < KB / 16; ++ks) {
             f16x8 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 U4H8 t;
-                t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * ROW_BYTES);
+                t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * KROW_BYTES);
                 af[i] = t.h;
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 U4H8 t;
-                t.u = *reinterpret_cast<const uint4*>(st + rd_b[ks] + j * 32 * ROW_BYTES);
+                t.u = *reinterpret_cast<const uint4*>(st + rd_b[ks] + j * 32 * KROW_BYTES);
                 bf[j] = t.h;
             }
 #pragma unroll
@@ -432,8 +445,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
                                             d.a1 ? p.a1_bytes : 0u);
         const i32x4 ws_w = make_rsrc_words(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-        const unsigned wave_dst = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 8 * ROW_BYTES);  // 8 rows per wave and pass
-        const int sw_slot = lslot ^ ((lrow >> 1) & 7);  // the lane fetches the logical slot that lives at its physical slot
+        const unsigned wave_dst = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 1024);  // one wave-wide DMA = 64 x 16 bytes of rows
+        const int sw_slot = lslot ^ lds_swz<KB>(lrow);  // the lane fetches the logical slot that lives at its physical slot
         unsigned dvoff_b[B_PASSES];
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
@@ -442,8 +455,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
         }
         unsigned dvoff_a[A_PASSES];
         // (tap, channel offset) of the next tile to issue, advanced incrementally: no per-tile integer division
-        int n_tap = (kt0 * BK) / ctot;
-        int n_cc = kt0 * BK - n_tap * ctot;
+        int n_tap = (kt0 * KB) / ctot;
+        int n_cc = kt0 * KB - n_tap * ctot;
         int n_ky = n_tap / d.ksize, n_kx = n_tap - n_ky * d.ksize;
         bool seg_dirty = true;
         bool n_second = false;
@@ -461,28 +474,28 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
                     dvoff_a[ps] = ok ? (unsigned)((pix * ld + sw_slot * 8) * 2) : OOB_OFFSET;
                 }
             }
-            const int kglob = t * BK;
+            const int kglob = t * KB;
             const unsigned soff_a = (unsigned)((second ? n_cc - d.c0 : n_cc) * 2);
             const unsigned soff_b = (unsigned)(kglob * 2);
             const unsigned dst_a = lds0 + (unsigned)(buf * STAGE_BYTES) + wave_dst;
-            const unsigned dst_b = dst_a + BM * ROW_BYTES;
+            const unsigned dst_b = dst_a + BM * KROW_BYTES;
             const i32x4 ra_src = second ? ws_a1 : ws_a0;
             if (ragged) {
                 const bool kbad = kglob + sw_slot * 8 >= d.K;
 #pragma unroll
                 for (int ps = 0; ps < A_PASSES; ++ps)
-                    dma16(ra_src, dst_a + ps * RPP * ROW_BYTES, kbad ? OOB_OFFSET : dvoff_a[ps], soff_a);
+                    dma16(ra_src, dst_a + ps * RPP * KROW_BYTES, kbad ? OOB_OFFSET : dvoff_a[ps], soff_a);
 #pragma unroll
                 for (int ps = 0; ps < B_PASSES; ++ps)
-                    dma16(ws_w, dst_b + ps * RPP * ROW_BYTES, kbad ? OOB_OFFSET : dvoff_b[ps], soff_b);
+                    dma16(ws_w, dst_b + ps * RPP * KROW_BYTES, kbad ? OOB_OFFSET : dvoff_b[ps], soff_b);
             } else {
 #pragma unroll
-                for (int ps = 0; ps < A_PASSES; ++ps) dma16(ra_src, dst_a + ps * RPP * ROW_BYTES, dvoff_a[ps], soff_a);
+                for (int ps = 0; ps < A_PASSES; ++ps) dma16(ra_src, dst_a + ps * RPP * KROW_BYTES, dvoff_a[ps], soff_a);
 #pragma unroll
-                for (int ps = 0; ps < B_PASSES; ++ps) dma16(ws_w, dst_b + ps * RPP * ROW_BYTES, dvoff_b[ps], soff_b);
+                for (int ps = 0; ps < B_PASSES; ++ps) dma16(ws_w, dst_b + ps * RPP * KROW_BYTES, dvoff_b[ps], soff_b);
             }
             // advance to the next K tile
-            n_cc += BK;
+            n_cc += KB;
             if (n_cc >= ctot) {
                 n_cc -= ctot;
                 ++n_tap;
@@ -679,15 +692,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB = 64>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
-    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+    constexpr int STAGE_BYTES = (BM + BN) * KB * 2;
     constexpr int EPI_BYTES = BM * (BN + 8) * 2;
     constexpr int NST = STAGES == 0 ? 2 : STAGES;
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             vd_set_error("vd_gemm_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -696,7 +709,7 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES>), grid, dim3(NT), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB>), grid, dim3(NT), LDS, stream, a);
     return vd_check_launch("vd_gemm_f16");
 }
 
@@ -869,6 +882,9 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int deep = deep_env ? (deep_env[0] - '0') : VD_GEMM_DEFAULT_DEEP;
     static const char* deep_blk_env = getenv("VD_GEMM_DEEP_MAXBLK");
     const int deep_maxblk = deep_blk_env ? atoi(deep_blk_env) : 400;
+    // (32-deep K tiles with a 4- or 5-stage ring -- launch_cfg<..., STAGES, 32> -- were measured 15-20 % slower than
+    // 64-deep / 2 stages on every UNet shape and on 4096^3 / 8192^3: the extra barrier per 32-deep step costs more than
+    // the deeper prefetch buys.  The kernel keeps the KB parameter; no 32-deep instance is built.)
     if (dma == 2 && deep >= 3 && grid_blocks <= deep_maxblk && a.kt_per_split >= (deep_blk_env ? 3 : 8) && (cfg == T128x64 || cfg == T64x64)) {
         if (cfg == T128x64) rc = deep == 4 ? launch_cfg<128, 64, 64, 32, 256, 4>(a, nsplit, stream) : launch_cfg<128, 64, 64, 32, 256, 3>(a, nsplit, stream);
         else rc = deep == 4 ? launch_cfg<64, 64, 32, 32, 256, 4>(a, nsplit, stream) : launch_cfg<64, 64, 32, 32, 256, 3>(a, nsplit, stream);
