@@ -222,7 +222,7 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
 }
 
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB = 64>
-__global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NT, (NT == 512 && WM * WN < 64 * 64 ? 4 : 2)) void gemm_f16_kernel(const GemmArgs p) {
     static_assert(KB == 64 || (KB == 32 && STAGES >= 2), "32-deep K tiles exist for the LDS-DMA ring only");
     constexpr int KROW_BYTES = KB * 2;  // one LDS row of a stage
     constexpr int SLOTS = KB / 8;       // 16-byte slots per row == threads cooperating on a row
@@ -380,13 +380,21 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 U4H8 t;
+#ifdef VD_GEMM_X_LDSBCAST  // experiment: every lane reads the same address (LDS bandwidth removed, instruction count kept)
+                t.u = *reinterpret_cast<const uint4*>(st + i * 32 * KROW_BYTES + ks * 32);
+#else
                 t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * KROW_BYTES);
+#endif
                 af[i] = t.h;
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 U4H8 t;
+#ifdef VD_GEMM_X_LDSBCAST
+                t.u = *reinterpret_cast<const uint4*>(st + BM * KROW_BYTES + j * 32 * KROW_BYTES + ks * 32);
+#else
                 t.u = *reinterpret_cast<const uint4*>(st + rd_b[ks] + j * 32 * KROW_BYTES);
+#endif
                 bf[j] = t.h;
             }
 #pragma unroll
@@ -515,7 +523,11 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void gemm_f16_kernel(const
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
+#ifdef VD_GEMM_X_NODMA  // experiment: no global traffic after the prologue (results are garbage)
+            if (i + D < nk && i < 2) issue_tile(kt0 + i + D, ibuf);
+#else
             if (i + D < nk) issue_tile(kt0 + i + D, ibuf);
+#endif
             compute_tile(cbuf);
             cbuf = (cbuf + 1 == STAGES) ? 0 : cbuf + 1;
             ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
@@ -722,7 +734,7 @@ extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
 }
 
 namespace {
-enum TileCfg { T128x128 = 0, T128x64 = 1, T64x64 = 2, T128x128w8 = 3, T128x64w8 = 4 };
+enum TileCfg { T128x128 = 0, T128x64 = 1, T64x64 = 2, T128x128w8 = 3, T128x64w8 = 4, T256x128 = 5, T128x256 = 6 };
 
 // validate + normalise the descriptor and pick tile shape / split factor
 int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) {
@@ -816,11 +828,25 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
                 const float t = model_us(c, ns);
                 if (t < best) { best = t; cfg = c.cfg; nsplit = ns; }
             }
+        // 256x128 block tiles (8 waves, one block per CU) move 25 % fewer bytes L2 -> LDS per FLOP, which is what bounds
+        // this kernel (tools/gemm_sweep.py: 8192^3 995 vs 895 TF/s); they only pay off once every CU gets several tiles
+        // (measured equal or slower on all UNet shapes, +10 % on the 512x512 VAE decoder convs)
+        if (d.split_k <= 0 && nsplit == 1 && d.N % 128 == 0 && (long)((d.M + 255) / 256) * (d.N / 128) * zb >= 1024) cfg = T256x128;
     }
     {   // developer override for tile experiments: VD_GEMM_TILE=0|1|2 (never set in production runs)
         static const char* ov = getenv("VD_GEMM_TILE");
         if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3')) {
             cfg = (TileCfg)(ov[0] - '0');
+            if (cfg == T256x128 || cfg == T128x256) {
+                nsplit = 1;
+                if (d.split_k <= 0 && can_split && a.kt_total >= 32) {
+                    const int bm2 = cfg == T256x128 ? 256 : 128, bn2 = cfg == T256x128 ? 128 : 256;
+                    const int tiles = ((d.M + bm2 - 1) / bm2) * ((d.N + bn2 - 1) / bn2) * zb;
+                    nsplit = 256 / tiles;  // one block per CU
+                    if (nsplit < 1) nsplit = 1;
+                    while (nsplit > 1 && a.kt_total / nsplit < 8) --nsplit;
+                }
+            } else
             if (d.split_k <= 0 && cfg <= T64x64) {  // re-plan the split for the forced tile
                 float best = 1e30f;
                 const int ns_max = (can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1;
@@ -836,6 +862,8 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     int bm = 128, bn = 128;
     if (cfg == T128x64 || cfg == T128x64w8) { bm = 128; bn = 64; }
     if (cfg == T64x64) { bm = 64; bn = 64; }
+    if (cfg == T256x128) { bm = 256; bn = 128; }
+    if (cfg == T128x256) { bm = 128; bn = 256; }
     a.tiles_m = (d.M + bm - 1) / bm;
     a.tiles_n = (d.N + bn - 1) / bn;
     if (nsplit > a.kt_total) nsplit = a.kt_total;
@@ -894,6 +922,8 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         case T128x64: rc = VD_LAUNCH(128, 64, 64, 32, 256); break;
         case T128x128w8: rc = VD_LAUNCH(128, 128, 32, 64, 512); break;
         case T128x64w8: rc = VD_LAUNCH(128, 64, 32, 32, 512); break;
+        case T256x128: rc = launch_cfg<256, 128, 64, 64, 512, 2>(a, nsplit, stream); break;
+        case T128x256: rc = launch_cfg<128, 256, 64, 64, 512, 2>(a, nsplit, stream); break;
         default: rc = VD_LAUNCH(64, 64, 32, 32, 256); break;
     }
 #undef VD_LAUNCH
