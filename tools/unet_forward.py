@@ -24,3 +24,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "time":
         e1.record()
         torch.cuda.synchronize()
         print("forward ms: %.3f" % (e0.elapsed_time(e1) / 10))
+if len(sys.argv) > 2 and sys.argv[2] == "sustain":
+    for n in (10, 50, 100):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            net.apply_model({"type": "image", "x": x}, t, ci)
+        e1.record()
+        torch.cuda.synchronize()
+        print("n=%d forward ms: %.3f" % (n, e0.elapsed_time(e1) / n))

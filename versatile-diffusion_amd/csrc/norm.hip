@@ -194,6 +194,104 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
     }
 }
 
+// ---- single-launch GroupNorm for the low-resolution levels -------------------------------------------------------------
+// One block per (batch element, channel slab), slab = lcm(channels per group, 8) channels = whole groups AND whole
+// 16-byte chunks.  When the slab of one sample (HW rows x slab channels) fits in the block's registers (<= GN_SLAB_ITEMS
+// 16-byte items per thread) the statistics never leave the block: x is read once, y written once, no scratch, one launch
+// instead of two (the two-kernel path above costs ~15 us
+// there regardless of size: two launches plus the slab-sum round trip).  Covers the 8x8 and 16x16 levels.
+constexpr int GN_SLAB_ITEMS = 12;  // measured: 24 rows per thread (32x32 levels, 64-128 blocks) is no faster than two launches
+
+template <int NITEM>
+__global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
+                                                      const f16* beta, f16* y, int HW, int C, int cg, int slab_chunks,
+                                                      int apply_silu, float inv_count, float eps) {
+    __shared__ float ls[16 * 2];  // <= 16 groups per slab
+    __shared__ float stat[16 * 2];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int ch0 = blockIdx.x * slab_chunks * 8;  // first channel of the slab
+    const int ngrp = slab_chunks * 8 / cg;
+    if (tid < 32) ls[tid] = 0.f;
+    __syncthreads();
+    // a thread keeps ONE 8-channel chunk of the slab and walks the rows: its per-channel sums stay in registers and
+    // reach LDS once (walking items linearly instead costs an LDS atomic pair per item on a handful of addresses)
+    const int rp = 256 / slab_chunks;                 // rows per pass
+    const int ck = tid % slab_chunks, rl = tid / slab_chunks;
+    const bool active = rl < rp;
+    const int ch = ch0 + ck * 8;
+    U4H8 t[NITEM];
+    if (active) {
+        // all loads unconditional and back to back; rows past HW re-read the last row and are weighted 0
+        float wgt[NITEM];
+#pragma unroll
+        for (int u = 0; u < NITEM; ++u) {
+            const int r = rl + u * rp;
+            wgt[u] = r < HW ? 1.f : 0.f;
+            t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (r < HW ? r : HW - 1), ch));
+        }
+        float sm[8], sq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm[i] = sq[i] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NITEM; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = (float)t[u].e[i] * wgt[u];
+                sm[i] += v;
+                sq[i] += v * v;
+            }
+        int gcur = (ck * 8) / cg;
+        float as = 0.f, aq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gi = (ck * 8 + i) / cg;
+            if (gi != gcur) {
+                atomicAdd(&ls[gcur * 2], as);
+                atomicAdd(&ls[gcur * 2 + 1], aq);
+                as = aq = 0.f;
+                gcur = gi;
+            }
+            as += sm[i];
+            aq += sq[i];
+        }
+        atomicAdd(&ls[gcur * 2], as);
+        atomicAdd(&ls[gcur * 2 + 1], aq);
+    }
+    __syncthreads();
+    if (tid < ngrp) {
+        const float mean = ls[tid * 2] * inv_count;
+        float var = ls[tid * 2 + 1] * inv_count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        stat[tid * 2] = mean;
+        stat[tid * 2 + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    if (active) {
+        U4H8 ga, be;
+        ga.u = *reinterpret_cast<const uint4*>(gamma + ch);
+        be.u = *reinterpret_cast<const uint4*>(beta + ch);
+        float sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gi = (ck * 8 + i) / cg;
+            sc[i] = stat[gi * 2 + 1] * (float)ga.e[i];
+            sh[i] = (float)be.e[i] - stat[gi * 2] * sc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < NITEM; ++u) {
+            const int r = rl + u * rp;
+            U4H8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = (float)t[u].e[i] * sc[i] + sh[i];
+                if (apply_silu) v = vd_silu(v);
+                o.e[i] = (f16)v;
+            }
+            if (r < HW) *reinterpret_cast<uint4*>(y + ((size_t)b * HW + r) * C + ch) = o.u;
+        }
+    }
+}
+
 // LayerNorm: one wave per row, row kept in registers (two-pass variance), C <= 2048, C % 8 == 0
 constexpr int LN_MAX_CH = 4;
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* gamma, const f16* beta, f16* y,
@@ -266,6 +364,25 @@ extern "C" int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int
     VD_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0, "vd_groupnorm_silu_f16: channel counts must be multiples of 8 (c0=%d c1=%d)", c0, c1);
     VD_REQUIRE(C <= GN_MAX_POS * 256 * 8, "vd_groupnorm_silu_f16: C=%d too large", C);
     const GnGeom g = gn_geom(HW, C);
+    {   // low-resolution levels: one block per (sample, channel slab), statistics stay in the block
+        const int cg = C / groups;
+        int slab = cg;  // lcm(cg, 8)
+        while (slab % 8 != 0) slab += cg;
+        const int slab_chunks = slab / 8;
+        if (C % slab == 0 && slab / cg <= 16 && slab_chunks <= 64 &&
+            (HW + 256 / slab_chunks - 1) / (256 / slab_chunks) <= GN_SLAB_ITEMS) {
+            const int items = (HW + 256 / slab_chunks - 1) / (256 / slab_chunks);  // rows per thread
+#define VD_GN_SLAB(N_)                                                                                                     \
+    hipLaunchKernelGGL(gn_slab_kernel<N_>, dim3(C / slab, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1, c1, \
+                       (const f16*)gamma, (const f16*)beta, (f16*)y, HW, C, cg, slab_chunks, apply_silu,                    \
+                       1.0f / ((float)HW * (float)cg), eps)
+            if (items <= 2) VD_GN_SLAB(2);
+            else if (items <= 6) VD_GN_SLAB(6);
+            else VD_GN_SLAB(12);
+#undef VD_GN_SLAB
+            return vd_check_launch("vd_groupnorm_silu_f16");
+        }
+    }
     float* part = stats;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1,
                        c1, part, HW, groups, g);
