@@ -104,8 +104,7 @@ def roofline_leg(net, batch, ctx, uctx, device):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pt = json.load(f)
-        key = dom.replace(">", ",2>") if dom.count(",") == 4 else dom  # table names carry the DMA-stage template arg
-        ent = pt["kernels"].get(key)
+        ent = pt["kernels"].get(dom)  # tools/pmc_traffic.py keys GEMM instantiations like this table does
         if ent:
             traffic, traffic_note = ent["hbm_side_bytes_per_launch"], "profiles/r01_pmc_traffic.json: " + pt["note"]
     except Exception:

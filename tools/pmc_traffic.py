@@ -1,0 +1,49 @@
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of tools/unet_forward.py) into the per-kernel
+HBM-side traffic table bench.py reads (profiles/rNN_pmc_traffic.json).
+
+usage: python tools/pmc_traffic.py <fetch_results.db> <write_results.db> > profiles/r01_pmc_traffic.json
+
+Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): gfx950 rocprofv3 reports half of the bytes of
+a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  GEMM instantiations are keyed without their
+(stages, K-depth) template arguments, matching the kernel names of bench.py's per-kernel table."""
+import collections, json, re, sqlite3, sys
+
+
+def norm(name):
+    m = re.search(r"(gemm_f16_kernel|attn_fwd_kernel)<([^>]*)>", name)
+    if m:
+        args = [a.strip() for a in m.group(2).split(",")]
+        if m.group(1) == "gemm_f16_kernel":
+            args = args[:5]
+        return "%s<%s>" % (m.group(1), ",".join(args))
+    m = re.search(r"(gn_partial_kernel|gn_apply_kernel|gn_slab_kernel|layernorm_kernel|splitk_reduce_kernel)", name)
+    return m.group(1) if m else None
+
+
+def collect(path, counter):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
+    ci = {c: i for i, c in enumerate(cols)}
+    acc = collections.defaultdict(list)
+    for r in cur.execute("select * from counters_collection"):
+        if r[ci["counter_name"]] != counter:
+            continue
+        k = norm(r[ci["kernel_name"]])
+        if k:
+            acc[k].append(r[ci["value"]])
+    return acc
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python tools/unet_forward.py 3",
+       "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 rocprofv3 reports half of a wide coalesced read "
+               "(MI355X_MICROARCH.md, HBM section); counters sit on the L2's fabric side, so Infinity-Cache hits are "
+               "included (upper bound on HBM bytes); WRITE_SIZE uncalibrated",
+       "kernels": {}}
+for k in sorted(fetch):
+    f = sum(fetch[k]) / len(fetch[k])
+    w = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
+    out["kernels"][k] = {"launches": len(fetch[k]), "fetch_size_kb_mean": round(f, 1), "write_size_kb_mean": round(w, 1),
+                         "hbm_side_bytes_per_launch": int((2 * f + w) * 1024)}
+print(json.dumps(out, indent=1, sort_keys=True))

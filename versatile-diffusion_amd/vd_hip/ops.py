@@ -202,7 +202,7 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
         out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
     nb = lib().vd_groupnorm_workspace_bytes(B, HW, C, groups)
     ws = workspace(nb, x.device, "gn")
-    with _Timed("groupnorm(2 kernels)", 0.0, 2.0 * B * HW * C * 3):
+    with _Timed("groupnorm (slab kernel or partial+apply)", 0.0, 2.0 * B * HW * C * 3):
         _check(lib().vd_groupnorm_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), B, HW,
                                            groups, float(eps), 1 if silu else 0, _stream()))
     return out
