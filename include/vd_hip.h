@@ -81,7 +81,8 @@ typedef struct VdGemmDesc {
  *   HF CLIP linear layers reached from lib/model_zoo/clip.py:58-61,95-100 */
 int vd_gemm_f16(const VdGemmDesc* desc, hipStream_t stream);
 size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
-/* Dry run of the launch heuristic: tile_cfg 0 = 128x128, 1 = 128x64, 2 = 64x64 block tile; nsplit = split-K factor.
+/* Dry run of the launch planner: tile_cfg 0 = 128x128, 1 = 128x64, 2 = 64x64, 3/4 = 8-wave 128x128 / 128x64 (GEGLU),
+ * 5 = 256x128, 6 = 128x256, 7 = 128x320 block tile; nsplit = split-K factor.
  * Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
 int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
 

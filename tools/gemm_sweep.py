@@ -18,6 +18,7 @@ SHAPES = [  # (B, H, W, Cin, Cout, ksize)
     (8, 16, 16, 640, 1280, 3), (8, 32, 32, 320, 640, 3),
     (8, 16, 16, 5120, 1280, 1), (8, 16, 16, 1280, 1280, 1), (8, 32, 32, 2560, 640, 1), (8, 64, 64, 1280, 320, 1),
     (8, 32, 32, 640, 640, 1), (8, 64, 64, 320, 320, 1), (8, 8, 8, 5120, 1280, 1),
+    (8, 64, 64, 320, 960, 1), (8, 64, 64, 320, 640, 1), (8, 64, 64, 640, 640, 3),
     (1, 64, 64, 4096, 4096, 1), (1, 64, 128, 8192, 8192, 1),
 ]
 SPLITS = [int(v) for v in os.environ.get("VD_SWEEP_SPLITS", "0,1,2,3,4,5,6,8,10,12,16").split(",")]
@@ -38,7 +39,10 @@ def timeit(fn, iters=30):
 
 print("tile override:", os.environ.get("VD_GEMM_TILE", "planner"))
 print("%-40s" % "shape (M N K)", " ".join("%7s" % ("p" if s == 0 else "s%d" % s) for s in SPLITS))
+FILT = os.environ.get("VD_SWEEP_FILTER")  # e.g. N=320
 for (B, H, W, Ci, Co, ks) in SHAPES:
+    if FILT and ("N=%d" % Co) != FILT:
+        continue
     x = torch.randn(B, H, W, Ci, device=dev, dtype=torch.float16)
     wt = torch.randn(Co, Ci, ks, ks, device=dev, dtype=torch.float16) * 0.02
     w = pack_conv_weight(wt) if ks == 3 else wt.reshape(Co, Ci).contiguous()

@@ -21,7 +21,8 @@ _prof = None
 PROFILE_SHAPES = False
 GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64,256>", "gemm_f16_kernel<128,64,64,32,256>", "gemm_f16_kernel<64,64,32,32,256>",
                      "gemm_f16_kernel<128,128,32,64,512>", "gemm_f16_kernel<128,64,32,32,512>",
-                     "gemm_f16_kernel<256,128,64,64,512>", "gemm_f16_kernel<128,256,64,64,512>")
+                     "gemm_f16_kernel<256,128,64,64,512>", "gemm_f16_kernel<128,256,64,64,512>",
+                     "gemm_f16_kernel<128,320,32,160,512>")
 
 
 def profile_begin():
