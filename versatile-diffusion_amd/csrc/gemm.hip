@@ -839,7 +839,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     }
     {   // developer override for tile experiments: VD_GEMM_TILE=0|1|2 (never set in production runs)
         static const char* ov = getenv("VD_GEMM_TILE");
-        if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3')) {
+        if (ov && (d.act != VD_ACT_GEGLU || ov[0] == '0' || ov[0] == '3' || ov[0] == '5' || ov[0] == '6')) {
             cfg = (TileCfg)(ov[0] - '0');
             if (cfg == T128x320) {
                 nsplit = 1;
