@@ -141,6 +141,39 @@ def test_full_unet_forward_vs_oracle(full, dev):
     assert rel_l2(e2, ref2) < FWD_TOL
 
 
+def test_bench_shape_forward_vs_oracle(full, dev):
+    """The exact shape bench.py times (BASELINE configs[1]): CFG batch 8, 64x64 latent, L = 77 -- so the tile / split
+    choices, the 128x320 tile of the 64x64 level and the attention kernel at N = 4096 are checked at full width."""
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((8, 4, 64, 64), generator=g)
+    c = torch.randn((8, 77, 768), generator=g) * 0.5
+    t = torch.tensor([981, 981, 501, 501, 21, 21, 1, 1])
+    with torch.no_grad():
+        ref = O.apply_model(sd, O.unet_plan(), x, t, c, c_type="text", global_ptr="image")
+    e = net.apply_model({"type": "image", "x": x.half().to(dev)}, t.to(dev), {"type": "text", "c": c.half().to(dev)})
+    assert rel_l2(e, ref) < FWD_TOL
+
+
+def test_c5_shape_dual_context_vs_oracle(full, dev):
+    """BASELINE configs[4] geometry: 96x96 latent (768x768 image, N = 9216 tokens), text (L = 77, ratio 0.4) + two
+    masked-image contexts concatenated (L = 514, ratio 0.6); ragged key tiles (514 = 8*64 + 2) and M = 9216 GEMMs."""
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn((1, 4, 96, 96), generator=g)
+    ct = torch.randn((1, 77, 768), generator=g) * 0.5
+    ci = torch.randn((1, 514, 768), generator=g) * 0.5
+    t = torch.tensor([641])
+    with torch.no_grad():
+        ref = O.apply_model_multicontext(sd, O.unet_plan(), x, t, [("text", ct, 0.4), ("image", ci, 0.6)])
+    e = net.apply_model_multicontext({"type": "image", "x": x.half().to(dev)}, t.to(dev), [
+        {"type": "text", "c": ct.half().to(dev), "ratio": 0.4}, {"type": "image", "c": ci.half().to(dev), "ratio": 0.6}])
+    assert e.shape == (1, 4, 96, 96)
+    assert rel_l2(e, ref) < FWD_TOL
+
+
 def test_full_vae_vs_oracle(full, dev):
     from oracle import vd_oracle as O
     net, sd = full
