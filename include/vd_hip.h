@@ -164,6 +164,17 @@ int vd_patchify_f16(const void* pixels, void* a, int B, int C, int H, int W, int
 int vd_scale_by_row_norm_f16(void* z, const void* ref, const int32_t* pool_idx, const float* row_scale, int B, int L,
                              int C, hipStream_t stream);
 
+/* CLIP image pre-processing on the device, bit-exact with the reference's host path (lib/model_zoo/clip.py:88-94:
+ * torchvision ToPILImage -> HuggingFace CLIPProcessor = Pillow 8-bit bicubic resize of the shortest edge, centre crop,
+ * rescale, normalise).  img [B,3,H,W]: img_kind 0 = float32 / 1 = float16 in [0,1] (quantised like ToPILImage:
+ * mul(255).byte()), 2 = uint8.  (rh, rw) = resized size, crop window (crop_t, crop_l, size).  hb/hk, vb/vk: Pillow's
+ * fixed-point taps per output column / row (device int32: bounds[out][2] = {first input index, taps}, kk[out][ks], 22
+ * fractional bits; ks = 0 and null tables when that axis is not resized).  norm_table: device float32 [256][3] =
+ * (level * (1/255) - mean[c]) / std[c].  tmp: B*3*H*size bytes of scratch.  out [B,3,size,size] float16. */
+int vd_clip_preprocess_f16(const void* img, int img_kind, int B, int H, int W, int rh, int rw, const int32_t* hb,
+                           const int32_t* hk, int hks, const int32_t* vb, const int32_t* vk, int vks, int crop_t, int crop_l,
+                           int size, const float* norm_table, uint8_t* tmp, void* out, hipStream_t stream);
+
 /* diagnostics */
 const char* vd_last_error(void);
 int vd_abi_version(void);

@@ -231,23 +231,19 @@ class CLIPImageContextEncoder(AbstractEncoder):
 
     def preprocess(self, images):
         """[B,3,H,W] in [0,1] (or a list of PIL images) -> CLIP pixel_values [B,3,224,224] fp16 on the device.
-        Input pre-processing (resize shortest side to 224 bicubic, centre crop, normalise), not part of the
-        kernel path; the reference does this on the host through PIL (clip.py:89-94)."""
+        The reference does this on the host (clip.py:88-94: ToPILImage -> CLIPProcessor = Pillow bicubic resize of the
+        shortest edge, centre crop, rescale, normalise); here it is `vd_clip_preprocess_f16` on the device, bit-exact with
+        that path (tests/test_clip_preprocess_*.py).  Tensors are quantised like ToPILImage (mul(255).byte()); PIL
+        images go in as the uint8 they are."""
         size = self.model.config["vision"]["image_size"]
         if not isinstance(images, torch.Tensor):
-            images = torch.stack([torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.float32) / 255.).permute(2, 0, 1)
-                                  for im in images])
-        x = images.to(device=self.get_device(), dtype=torch.float32)
-        h, w = x.shape[-2:]
-        s = size / min(h, w)
-        nh, nw = max(size, round(h * s)), max(size, round(w * s))
-        if (nh, nw) != (h, w):
-            x = F.interpolate(x, size=(nh, nw), mode="bicubic", antialias=True, align_corners=False).clamp(0, 1)
-        t, l = (nh - size) // 2, (nw - size) // 2
-        x = x[..., t:t + size, l:l + size]
-        mean = torch.tensor(CLIP_MEAN, device=x.device).view(1, 3, 1, 1)
-        std = torch.tensor(CLIP_STD, device=x.device).view(1, 3, 1, 1)
-        return ((x - mean) / std).to(torch.float16).contiguous()
+            sizes = {im.size for im in images}
+            assert len(sizes) == 1, "a batch of PIL images must share one size"
+            images = torch.stack([torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.uint8)).permute(2, 0, 1) for im in images])
+        x = images.to(device=self.get_device())
+        if x.dtype not in (torch.float32, torch.float16, torch.uint8):
+            x = x.float()
+        return ops.clip_preprocess(x, size)
 
     def vtoken_mask(self, masks):
         """[B,1,H,W] mask -> per-token weights [B, 257] = [global mean | 14x14 patch means] of the mask resized to

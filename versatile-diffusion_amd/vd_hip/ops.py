@@ -377,6 +377,37 @@ def scale_by_row_norm_(z, *, ref=None, pool_idx=None, row_scale=None):
     return z
 
 
+_pre_tables = {}
+
+
+def clip_preprocess(images, size=224):
+    """[B,3,H,W] float32 / float16 in [0,1] (quantised like ToPILImage) or uint8 -> CLIP pixel_values [B,3,size,size]
+    fp16: Pillow-exact bicubic resize of the shortest edge, centre crop, rescale, normalise (vd_clip_preprocess_f16)."""
+    from . import resample as R
+    assert images.dim() == 4 and images.shape[1] == 3 and images.is_cuda
+    kind = {torch.float32: 0, torch.float16: 1, torch.uint8: 2}[images.dtype]
+    img = images.contiguous()
+    B, _, H, W = img.shape
+    rh, rw = R.resize_output_size(H, W, size)
+    dev = img.device
+    key = (dev.index, H, W, size)
+    tabs = _pre_tables.get(key)
+    if tabs is None:
+        def taps(n_in, n_out):
+            if n_in == n_out:
+                return None, None, 0
+            b, k, ks = R.pil_bicubic_taps(n_in, n_out)
+            return torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev), ks
+        tabs = (taps(W, rw), taps(H, rh), torch.from_numpy(R.clip_norm_table()).to(dev))
+        _pre_tables[key] = tabs
+    (hb, hk, hks), (vb, vk, vks), table = tabs
+    tmp = workspace(B * 3 * H * size, dev, "clip_pre")
+    out = torch.empty((B, 3, size, size), dtype=torch.float16, device=dev)
+    _check(lib().vd_clip_preprocess_f16(_ptr(img), kind, B, H, W, rh, rw, _ptr(hb), _ptr(hk), hks, _ptr(vb), _ptr(vk), vks,
+                                        (rh - size) // 2, (rw - size) // 2, size, _ptr(table), _ptr(tmp), _ptr(out), _stream()))
+    return out
+
+
 def probe_lds_tr16(addr_bytes):
     """addr_bytes: (64,) int32 per-lane LDS byte addresses -> (64, 4) int16 values read by ds_read_b64_tr_b16."""
     _req(addr_bytes, "addr_bytes", torch.int32)
