@@ -175,6 +175,10 @@ int vd_clip_preprocess_f16(const void* img, int img_kind, int B, int H, int W, i
                            const int32_t* hk, int hks, const int32_t* vb, const int32_t* vk, int vks, int crop_t, int crop_l,
                            int size, const float* norm_table, uint8_t* tmp, void* out, hipStream_t stream);
 
+/* Decoded image [B,3,H,W] (img_kind 0 = float32, 1 = float16, values in [0,1]) -> uint8 [B,H,W,3], the arithmetic of
+ * torchvision ToPILImage on the output of vae_decode (reference app.py:319): mul(255) in the tensor's dtype, .byte(). */
+int vd_image_to_u8(const void* img, int img_kind, int B, int H, int W, uint8_t* out, hipStream_t stream);
+
 /* diagnostics */
 const char* vd_last_error(void);
 int vd_abi_version(void);

@@ -61,3 +61,14 @@ def test_encoder_preprocess_uses_device_path(dev):
     pv = enc.preprocess(torch.from_numpy(img)[None])
     assert pv.shape == (1, 3, 224, 224) and pv.dtype == torch.float16
     assert np.array_equal(pv.cpu().numpy()[0], CP.clip_preprocess(img)[1].astype(np.float16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_image_to_u8_matches_topilimage_arithmetic(dev, dtype):
+    """ToPILImage on a float tensor is `pic.mul(255).byte()` in the tensor's dtype, then CHW -> HWC."""
+    from vd_hip import ops
+    x = torch.rand((2, 3, 64, 96), generator=torch.Generator().manual_seed(4)).to(dtype)
+    x[0, :, 0, :4] = torch.tensor([0.0, 1.0, 0.5, 254.999 / 255]).to(dtype)
+    ref = x.mul(255).byte().permute(0, 2, 3, 1).contiguous()
+    out = ops.image_to_u8(x.to(dev)).cpu()
+    assert torch.equal(out, ref)

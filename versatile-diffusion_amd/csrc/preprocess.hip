@@ -73,7 +73,30 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* tmp
     out[i] = (f16)table[lv * 3 + c];
 }
 
+// decoded image [B,3,H,W] (float32 / float16 in [0,1]) -> uint8 [B,H,W,3]: torchvision ToPILImage = mul(255).byte() in the
+// tensor's own dtype, then CHW -> HWC (reference app.py:319 on the output of vae_decode)
+template <int KIND>
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const void* img, uint8_t* out, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // output index: ((b * HW + p) * 3 + c)
+    if (i >= total) return;
+    const int c = (int)(i % 3);
+    const size_t bp = i / 3;
+    const size_t b = bp / HW, p = bp - b * HW;
+    out[i] = (uint8_t)load_level<KIND>(img, (b * 3 + c) * (size_t)HW + p);
+}
+
 }  // namespace
+
+extern "C" int vd_image_to_u8(const void* img, int img_kind, int B, int H, int W, uint8_t* out, hipStream_t stream) {
+    VD_REQUIRE(img && out, "vd_image_to_u8: null pointer");
+    VD_REQUIRE(B > 0 && H > 0 && W > 0, "vd_image_to_u8: empty input");
+    VD_REQUIRE(img_kind == 0 || img_kind == 1, "vd_image_to_u8: img_kind must be 0 (f32) or 1 (f16)");
+    const size_t total = (size_t)B * H * W * 3;
+    const unsigned g = (unsigned)((total + 255) / 256);
+    if (img_kind == 0) hipLaunchKernelGGL(image_to_u8_kernel<0>, dim3(g), dim3(256), 0, stream, img, out, H * W, total);
+    else hipLaunchKernelGGL(image_to_u8_kernel<1>, dim3(g), dim3(256), 0, stream, img, out, H * W, total);
+    return vd_check_launch("vd_image_to_u8");
+}
 
 extern "C" int vd_clip_preprocess_f16(const void* img, int img_kind, int B, int H, int W, int rh, int rw, const int32_t* hb,
                                       const int32_t* hk, int hks, const int32_t* vb, const int32_t* vk, int vks, int crop_t,

@@ -377,6 +377,16 @@ def scale_by_row_norm_(z, *, ref=None, pool_idx=None, row_scale=None):
     return z
 
 
+def image_to_u8(images):
+    """[B,3,H,W] float32 / float16 in [0,1] -> uint8 [B,H,W,3] exactly as torchvision ToPILImage quantises (app.py:319)."""
+    assert images.dim() == 4 and images.shape[1] == 3 and images.is_cuda and images.dtype in (torch.float32, torch.float16)
+    img = images.contiguous()
+    B, _, H, W = img.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=img.device)
+    _check(lib().vd_image_to_u8(_ptr(img), 0 if img.dtype == torch.float32 else 1, B, H, W, _ptr(out), _stream()))
+    return out
+
+
 _pre_tables = {}
 
 
