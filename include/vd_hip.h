@@ -95,6 +95,13 @@ int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int c1, const 
                           hipStream_t stream);
 size_t vd_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 
+/* GroupNorm(groups) [+ SiLU] of the 0-D (text-latent) data flow: FCBlock normalises the flattened [C, sdim] vector of a
+ * sample with one affine pair per flat element (reference openaimodel.py:2084-2141 with the [C, sdim, 1] -> C*sdim view
+ * of FCBlock_MultiDim, :2295-2332).  x0 (++ x1 on channels): [B, S, C] channels-last; gamma / beta: [S, C] (the
+ * reference's c * sdim + s order re-ordered once at load); y: [B, S, C]. */
+int vd_groupnorm0d_silu_f16(const void* x0, int c0, const void* x1, int c1, const void* gamma, const void* beta, void* y,
+                            int B, int S, int groups, float eps, int apply_silu, hipStream_t stream);
+
 /* LayerNorm over the last dim of [rows][C]. Replaces nn.LayerNorm in BasicTransformerBlock
  * (lib/model_zoo/attention.py:205-207) and the HF CLIP layer norms. */
 int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,

@@ -127,6 +127,16 @@ def main():
              state_keys=np.array(sorted(net.state_dict().keys())),
              state_shapes=np.array([json.dumps(list(net.state_dict()[k].shape)) for k in sorted(net.state_dict().keys())]))
 
+    # ---- B2. text-latent (0-D) data flow: data blocks of diffuser['text'], context blocks of the context's type -------
+    x0d = seeded((2, 128), 21)
+    with torch.no_grad():
+        e0_img = net.apply_model({"type": "text", "x": x0d}, t, {"type": "image", "c": c_img})
+        e0_text = net.apply_model({"type": "text", "x": x0d}, t, {"type": "text", "c": c_text})
+    # (apply_model_multicontext takes time_embed from diffuser[x_type] (vd.py:415-417); the 'text' diffuser is built
+    #  without global layers, so the reference itself cannot run a multi-context text flow)
+    np.savez_compressed(os.path.join(GOLD, "unet0d_tiny.npz"), x=x0d.numpy(), t=t.numpy(), c_text=c_text.numpy(),
+                        c_img=c_img.numpy(), eps_image=e0_img.numpy(), eps_text=e0_text.numpy())
+
     # ---- C. DDIM loops ------------------------------------------------------------------------
     net.device = "cpu"
     sampler = ref.ddim.DDIMSampler(net)

@@ -190,6 +190,68 @@ def unet_plan(in_channels=4, model_channels=320, out_channels=4, num_res_blocks=
             "model_channels": model_channels}
 
 
+def fcblock(sd, p, x, emb):
+    """FCBlock_MultiDim.forward / FCBlock._forward (openaimodel.py:2084-2141, 2295-2332): the [C, sdim, 1] tail of x is
+    flattened to C*sdim channels of a 1x1 map; GN32 (eps 1e-5) -> SiLU -> 1x1 conv, + emb, GN32 -> SiLU -> 1x1 conv,
+    + skip(x)."""
+    shape = x.shape
+    xf = x.reshape(shape[0], -1, 1, 1)
+    h = _conv(sd, p + ".in_layers.2", F.silu(_gn(sd, p + ".in_layers.0", xf, 1e-5)))
+    emb_out = _lin(sd, p + ".emb_layers.1", F.silu(emb))
+    h = h + emb_out[:, :, None, None]
+    h = _conv(sd, p + ".out_layers.3", F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5)))
+    if (p + ".skip_connection.weight") in sd:
+        xf = _conv(sd, p + ".skip_connection", xf)
+    return xf + h          # [B, Cout*sdim, 1, 1]; the caller views it as [B, Cout, sdim, 1]
+
+
+def linear_multidim(sd, p, x, out_shape):
+    """Linear_MultiDim.forward (openaimodel.py:2275-2293): flatten the trailing feature dims, nn.Linear, view back."""
+    return _lin(sd, p, x.reshape(x.shape[0], -1)).view(x.shape[0], *out_shape)
+
+
+def unet0d_plan(input_channels=768, model_channels=320, output_channels=768, num_noattn_blocks=(2, 2, 2, 2),
+                channel_mult=(1, 2, 4, 8), second_dim=(4, 4, 4, 4), with_attn=(True, True, True, False), num_heads=8,
+                num_head_channels=None, **_ignored):
+    """Structure of UNetModel0D_Next.__init__ (openaimodel.py:2815-2966) as data; same shape of result as unet_plan.
+    Data entries carry the [C, sdim, 1] output shape of the block."""
+    def heads_of(ch):
+        return num_heads if num_head_channels is None else ch // num_head_channels
+
+    data, ctx, order = [], [], []
+    cur = [model_channels, second_dim[0], 1]
+    data.append(("lin_md", cur)); order += ["d", "save_hidden_feature"]
+    chans = [cur]
+    for level, (mult, sdim) in enumerate(zip(channel_mult, second_dim)):
+        for _ in range(num_noattn_blocks[level]):
+            cur = [mult * model_channels, sdim, 1]
+            data.append(("fc", cur)); order.append("d")
+            if with_attn[level]:
+                ctx.append((cur[0], heads_of(cur[0]))); order.append("c")
+            chans.append(cur); order.append("save_hidden_feature")
+        if level != len(channel_mult) - 1:
+            data.append(("lin_md", cur)); order += ["d", "save_hidden_feature"]
+            chans.append(cur)
+    i_order, order = order, []
+    data.append(("fc", cur)); order.append("d")
+    ctx.append((cur[0], heads_of(cur[0]))); order.append("c")
+    data.append(("fc", cur)); order.append("d")
+    m_order, order = order, []
+    for level, (mult, sdim) in list(enumerate(zip(channel_mult, second_dim)))[::-1]:
+        for _ in range(num_noattn_blocks[level] + 1):
+            order.append("load_hidden_feature")
+            chans.pop()
+            cur = [mult * model_channels, sdim, 1]
+            data.append(("fc", cur)); order.append("d")
+            if with_attn[level]:
+                ctx.append((cur[0], heads_of(cur[0]))); order.append("c")
+        if level != 0:
+            data.append(("lin_md", cur)); order.append("d")
+    data.append(("out0d", [output_channels])); order.append("d")
+    return {"data": data, "ctx": ctx, "i_order": i_order, "m_order": m_order, "o_order": order,
+            "model_channels": model_channels}
+
+
 def _data_block(sd, p, kind, h, emb):
     """TimestepEmbedSequential dispatch (openaimodel.py:78-86) for the data blocks of the 2D UNet."""
     if kind == "conv_in":
@@ -226,7 +288,15 @@ def apply_model_multicontext(sd, plan, x, timesteps, contexts, x_type="image", g
 
     def run_d(h):
         i = next(di)
-        return _data_block(sd, "diffuser.%s.data_blocks.%d" % (x_type, i), plan["data"][i][0], h, emb)
+        kind = plan["data"][i][0]
+        p = "diffuser.%s.data_blocks.%d" % (x_type, i)
+        if kind == "lin_md":      # plain layer inside the TimestepEmbedSequential (openaimodel.py:78-86)
+            return linear_multidim(sd, p + ".0", h, plan["data"][i][1])
+        if kind == "fc":
+            return fcblock(sd, p + ".0", h, emb).view(h.shape[0], *plan["data"][i][1])
+        if kind == "out0d":
+            return linear_multidim(sd, p + ".0.2", F.silu(_gn(sd, p + ".0.0", h, 1e-5)), plan["data"][i][1])
+        return _data_block(sd, p, kind, h, emb)
 
     def run_c(h):
         j = next(ci)

@@ -41,6 +41,26 @@ def test_mfma_layout_probe(ops, dev):
     assert a_k.tolist() == list(range(16)), "A/B k-slot pairing is not the identity: %s" % a_k.tolist()
 
 
+@pytest.mark.parametrize("B,S,c0,c1,silu", [(2, 4, 320, 0, True), (3, 4, 1280, 1280, True), (1, 4, 64, 64, False), (8, 4, 640, 320, True)])
+def test_groupnorm0d(ops, dev, B, S, c0, c1, silu):
+    """FCBlock's GroupNorm: statistics per (sample, channel group) over all S positions, affine per (s, c)."""
+    x0 = rnd((B, S, c0), dev, 2.0, 40) + 0.3
+    x1 = rnd((B, S, c1), dev, 1.0, 41) if c1 else None
+    C = c0 + c1
+    gamma = rnd((S, C), dev, 0.5, 42) + 1.0
+    beta = rnd((S, C), dev, 0.5, 43)
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    # reference formulation: flatten [C, S] (c-major) to C*S channels of a 1x1 map, 32 groups, affine per flat channel
+    xf = x.float().permute(0, 2, 1).reshape(B, C * S, 1, 1)
+    ref = F.group_norm(xf, 32, gamma.float().t().reshape(-1), beta.float().t().reshape(-1), 1e-5)
+    ref = ref.view(B, C, S).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm0d_silu(x0, gamma, beta, x1=x1, groups=32, eps=1e-5, silu=silu)
+    assert out.shape == (B, S, C)
+    assert rel_l2(out, ref) < 2e-3
+
+
 def test_lds_transpose_read_probe(ops, dev):
     """ds_read_b64_tr_b16 semantics the attention kernel's V operand is built on: in every 16-lane group, lane i supplies
     the address of 4 contiguous halfs = row (i>>2), column quad (i&3) of a [4][16] block (row stride free), and receives

@@ -102,6 +102,23 @@ def test_unet_tiny_forward(meta, tiny_sd):
     assert float(np.abs(g["eps_text"]).mean()) > 1e-2  # the synthetic weights do not zero the output
 
 
+def test_unet0d_tiny_forward(meta, tiny_sd):
+    """Text-latent (0-D) data flow: FCBlock_MultiDim / Linear_MultiDim data blocks of diffuser['text'] with
+    image- or text-typed context blocks, time_embed through the global pointer."""
+    g = load("unet0d_tiny.npz")
+    plan = O.unet0d_plan(**meta["unet0d"])
+    full = O.unet0d_plan()
+    assert len(full["data"]) == 30 and len(full["ctx"]) == 16 and full["i_order"] == O.unet_plan()["i_order"]
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        e_img = O.apply_model(tiny_sd, plan, x, t, T(g["c_img"]), x_type="text", c_type="image", global_ptr="image")
+        e_text = O.apply_model(tiny_sd, plan, x, t, T(g["c_text"]), x_type="text", c_type="text", global_ptr="image")
+    assert e_img.shape == (2, 128)
+    assert rel(e_img, g["eps_image"]) < 1e-5
+    assert rel(e_text, g["eps_text"]) < 1e-5
+    assert float(np.abs(g["eps_image"]).mean()) > 1e-2
+
+
 def test_ddim_tiny(meta, tiny_sd):
     g = load("ddim_tiny.npz")
     plan = O.unet_plan(**meta["unet2d"])

@@ -47,6 +47,39 @@ def test_tiny_unet_vs_golden(tiny, dev):
     assert e32.dtype == torch.float32 and rel_l2(e32, g["eps_text"]) < FWD_TOL
 
 
+def test_tiny_text_latent_flow_vs_golden(tiny, dev):
+    """0-D (text-latent) data flow, SURVEY 8f-4: data blocks of diffuser['text'], context blocks of the context's type."""
+    g = load_gold("unet0d_tiny.npz")
+    x, t = T(g["x"], dev), torch.from_numpy(g["t"]).to(dev)
+    e = tiny.apply_model({"type": "text", "x": x}, t, {"type": "image", "c": T(g["c_img"], dev)})
+    assert e.shape == x.shape and e.dtype == torch.float16
+    assert rel_l2(e, g["eps_image"]) < FWD_TOL
+    e = tiny.apply_model({"type": "text", "x": x}, t, {"type": "text", "c": T(g["c_text"], dev)})
+    assert rel_l2(e, g["eps_text"]) < FWD_TOL
+
+
+def test_tiny_text_latent_ddim_vs_oracle(tiny, dev):
+    """DDIM loop over the 768-d style text latent ([B, D] instead of [B, 4, h, w]) with CFG, image context."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import synth, vd_oracle as O
+    m = meta()
+    g = load_gold("unet0d_tiny.npz")
+    sd = synth.synth_state_dict(synth.shapes_of(tiny), m["seed"])
+    sd.update(O.register_schedule())
+    xT = torch.randn((2, 128), generator=torch.Generator().manual_seed(31))
+    c, u = torch.from_numpy(g["c_img"]), torch.zeros_like(torch.from_numpy(g["c_img"]))
+    with torch.no_grad():
+        zr, _ = O.ddim_sample(sd, O.unet0d_plan(**m["unet0d"]), sd["alphas_cumprod"], xT,
+                              [{"type": "image", "conditioning": c, "unconditional_conditioning": u}], 5, 4.0,
+                              x_type="text", global_ptr="image")
+    z, _ = DDIMSampler(tiny).sample(steps=5, shape=[2, 128], x_info={"type": "text", "xt": xT.half().to(dev)},
+                                    c_info={"type": "image", "conditioning": c.half().to(dev),
+                                            "unconditional_conditioning": u.half().to(dev),
+                                            "unconditional_guidance_scale": 4.0}, eta=0., verbose=False)
+    assert z.shape == (2, 128)
+    assert rel_l2(z, zr) < LATENT_TOL
+
+
 def test_tiny_ddim_vs_golden(tiny, dev, monkeypatch):
     from lib.model_zoo.ddim import DDIMSampler
     g = load_gold("ddim_tiny.npz")
@@ -358,3 +391,32 @@ def test_checkpoint_ingestion(tmp_path, dev):
     assert rel_l2(out1, out0) > 1e-2
     ref_net.load_state_dict(sd, strict=True)   # in-place reload must invalidate the packed-weight cache
     assert rel_l2(ref_net.decode(z), out1) < 1e-3
+
+
+def test_full_text_latent_flow_vs_oracle(dev):
+    """Full-width openai_unet_0d_v1_dc (1.44 B data + 0.27 B context parameters): one forward of the text-latent flow with
+    an image context, CFG batch 2, against the CPU oracle."""
+    from lib.cfg_helper import CfgDict, model_cfg_bank
+    from lib.model_zoo import get_model
+    from oracle import vd_oracle as O
+    bank = model_cfg_bank()
+    cfg = CfgDict(type="vd_v2_0", args=CfgDict(
+        vae_cfg_list=[], ctx_cfg_list=[["image", "ctx-image-placeholder"], ["text", "ctx-text-placeholder"]],
+        diffuser_cfg_list=[["image", bank("openai_unet_2d_v1")], ["text", bank("openai_unet_0d_v1_dc")]],
+        global_layer_ptr="image", latent_scale_factor={"image": 0.18215}, beta_linear_start=0.00085,
+        beta_linear_end=0.012, timesteps=1000, use_ema=False))
+    net = get_model()(cfg, verbose=False)
+    assert sum(p.numel() for p in net.diffuser["text"].parameters()) == 1706797888
+    sd = synth_into(net, 13)
+    net = net.half()
+    net.to(dev)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn((2, 768), generator=g)
+    c = torch.randn((2, 257, 768), generator=g) * 0.5
+    t = torch.tensor([801, 801])
+    with torch.no_grad():
+        plan = O.unet0d_plan(**dict(bank("openai_unet_0d_v1_dc").args))
+        ref = O.apply_model(sd, plan, x, t, c, x_type="text", c_type="image", global_ptr="image")
+    e = net.apply_model({"type": "text", "x": x.half().to(dev)}, t.to(dev), {"type": "image", "c": c.half().to(dev)})
+    assert e.shape == (2, 768)
+    assert rel_l2(e, ref) < FWD_TOL

@@ -822,8 +822,18 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     TileCfg cfg = T64x64;
     int nsplit = 1;
     if (d.act == VD_ACT_GEGLU) cfg = T128x128w8;  // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others
-    else if (d.M < 96 || d.N < 96) cfg = T64x64;
-    else {
+    else if (d.M < 96 || d.N < 96) {
+        // small-M weight streaming (time-embedding MLPs, the 0-D text-latent flow: M = CFG batch, N x K up to 5120 x
+        // 10240): 64x64 tiles, but split K until the grid covers the chip -- the weight matrix is the only traffic
+        cfg = T64x64;
+        float best = 1e30f;
+        const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 16) ? VD_MAX_SPLIT_K / 2 : 1);
+        for (int ns = (d.split_k > 0 ? d.split_k : 1); ns <= ns_max; ++ns) {
+            if (ns > 1 && a.kt_total / ns < 4) break;
+            const float t = model_us(cands[2], ns);
+            if (t < best) { best = t; nsplit = ns; }
+        }
+    } else {
         float best = 1e30f;
         const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1);
         for (const Cand& c : cands)

@@ -292,6 +292,70 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
     }
 }
 
+// ---- GroupNorm of the 0-D (text-latent) data flow ---------------------------------------------------------------------
+// FCBlock (reference openaimodel.py:2084-2141) normalises the FLATTENED [C, sdim] vector of a sample with 32 groups and
+// an affine per flat element.  Here a sample is [S = sdim][C] channels-last (optionally two tensors concatenated on C),
+// so a group is a channel range over all S positions -- the statistics of a regular GroupNorm with HW = S -- but gamma /
+// beta are indexed [s][c] (re-ordered once at load from the reference's c * sdim + s).  One block per sample: the whole
+// sample is <= 10240 elements.
+__global__ __launch_bounds__(256) void gn0d_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
+                                                   const f16* beta, f16* y, int S, int groups, int apply_silu, float eps) {
+    __shared__ float ls[64 * 2];
+    __shared__ float stat[64 * 2];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int C = c0 + c1, C8 = C / 8, cg = C / groups;
+    if (tid < groups * 2) ls[tid] = 0.f;
+    __syncthreads();
+    const int nchunk = S * C8;
+    for (int i = tid; i < nchunk; i += 256) {
+        const int s = i / C8, cc = i - s * C8;
+        U4H8 t;
+        t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * S + s, cc * 8));
+        int gcur = (cc * 8) / cg;
+        float as = 0.f, aq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gi = (cc * 8 + k) / cg;
+            if (gi != gcur) {
+                atomicAdd(&ls[gcur * 2], as);
+                atomicAdd(&ls[gcur * 2 + 1], aq);
+                as = aq = 0.f;
+                gcur = gi;
+            }
+            const float v = (float)t.e[k];
+            as += v;
+            aq += v * v;
+        }
+        atomicAdd(&ls[gcur * 2], as);
+        atomicAdd(&ls[gcur * 2 + 1], aq);
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const float inv = 1.0f / ((float)S * (float)cg);
+        const float mean = ls[tid * 2] * inv;
+        float var = ls[tid * 2 + 1] * inv - mean * mean;
+        if (var < 0.f) var = 0.f;
+        stat[tid * 2] = mean;
+        stat[tid * 2 + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int i = tid; i < nchunk; i += 256) {
+        const int s = i / C8, cc = i - s * C8;
+        U4H8 t, ga, be, o;
+        t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * S + s, cc * 8));
+        ga.u = *reinterpret_cast<const uint4*>(gamma + (size_t)s * C + cc * 8);
+        be.u = *reinterpret_cast<const uint4*>(beta + (size_t)s * C + cc * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gi = (cc * 8 + k) / cg;
+            float v = ((float)t.e[k] - stat[gi * 2]) * stat[gi * 2 + 1] * (float)ga.e[k] + (float)be.e[k];
+            if (apply_silu) v = vd_silu(v);
+            o.e[k] = (f16)v;
+        }
+        *reinterpret_cast<uint4*>(y + ((size_t)b * S + s) * C + cc * 8) = o.u;
+    }
+}
+
 // LayerNorm: one wave per row, row kept in registers (two-pass variance), C <= 2048, C % 8 == 0
 constexpr int LN_MAX_CH = 4;
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* gamma, const f16* beta, f16* y,
@@ -390,6 +454,19 @@ extern "C" int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int
                        (const f16*)gamma, (const f16*)beta, part, (f16*)y, HW, groups, apply_silu,
                        1.0f / ((float)HW * (float)(C / groups)), eps, g);
     return vd_check_launch("vd_groupnorm_silu_f16");
+}
+
+extern "C" int vd_groupnorm0d_silu_f16(const void* x0, int c0, const void* x1, int c1, const void* gamma, const void* beta,
+                                       void* y, int B, int S, int groups, float eps, int apply_silu, hipStream_t stream) {
+    if (x1 == nullptr) c1 = 0;
+    const int C = c0 + c1;
+    VD_REQUIRE(x0 && gamma && beta && y, "vd_groupnorm0d_silu_f16: null pointer");
+    VD_REQUIRE(B > 0 && S > 0 && C > 0, "vd_groupnorm0d_silu_f16: empty input");
+    VD_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0, "vd_groupnorm0d_silu_f16: bad groups=%d for C=%d", groups, C);
+    VD_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0, "vd_groupnorm0d_silu_f16: channel counts must be multiples of 8 (c0=%d c1=%d)", c0, c1);
+    hipLaunchKernelGGL(gn0d_kernel, dim3(B), dim3(256), 0, stream, (const f16*)x0, c0, (const f16*)x1, c1, (const f16*)gamma,
+                       (const f16*)beta, (f16*)y, S, groups, apply_silu, eps);
+    return vd_check_launch("vd_groupnorm0d_silu_f16");
 }
 
 extern "C" int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,

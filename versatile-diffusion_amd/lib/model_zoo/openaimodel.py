@@ -305,9 +305,29 @@ class UNetModel2D_Next(nn.Module, PackCache):
         return run_unet(self, [(self.context_blocks, context, 1.0, None)], x, emb)
 
 
-class Linear_MultiDim(nn.Linear):
-    """Parameter container for the 0-D (text-latent) data flow; same keys/shapes as the reference
-    (openaimodel.py:2275-2293).  The text *data* flow is outside this package's hot path."""
+def _md_perm(w, out_md, in_md):
+    """Re-order a dense weight [prod(out_md), prod(in_md)] from the reference's flattening of a [C, sdim, 1] feature
+    (index c * sdim + s) to this package's channels-last one (s * C + c) on whichever side is multi-dimensional."""
+    o_all, i_all = w.shape
+    if len(out_md) == 3:
+        co, so = out_md[0], out_md[1]
+        w = w.view(co, so, i_all).permute(1, 0, 2).reshape(o_all, i_all)
+    if len(in_md) == 3:
+        ci, si = in_md[0], in_md[1]
+        w = w.view(o_all, ci, si).permute(0, 2, 1).reshape(o_all, i_all)
+    return w.contiguous()
+
+
+def _md_perm_vec(v, md):
+    if v is None or len(md) != 3:
+        return v
+    return v.view(md[0], md[1]).t().reshape(-1).contiguous()
+
+
+class Linear_MultiDim(nn.Linear, PackCache):
+    """Dense layer between multi-dimensional features (reference openaimodel.py:2275-2293), parameters in the
+    reference's shapes.  Activations here are channels-last: a [C, sdim, 1] feature is held as [B, sdim, 1, C], so the
+    weight is re-ordered once (cached) and the layer is one `vd_gemm_f16` on [B, prod(in)]."""
 
     def __init__(self, in_features, out_features, *args, **kwargs):
         in_features = [in_features] if isinstance(in_features, int) else list(in_features)
@@ -316,12 +336,23 @@ class Linear_MultiDim(nn.Linear):
         self.out_features_multidim = out_features
         super().__init__(int(np.prod(in_features)), int(np.prod(out_features)), *args, **kwargs)
 
+    def _w(self):
+        return self._packed("w", (self.weight, self.bias), lambda: (
+            _md_perm(_h(self.weight), self.out_features_multidim, self.in_features_multidim),
+            _md_perm_vec(_h(self.bias), self.out_features_multidim)))
+
     def forward(self, x):
-        raise NotImplementedError("text-latent data flow (UNetModel0D data blocks) is not on the image sampling path")
+        w, b = self._w()
+        B = x.shape[0]
+        y = ops.linear(x.reshape(B, -1), w, b)
+        om = self.out_features_multidim
+        return y.view(B, om[1], om[2], om[0]) if len(om) == 3 else y
 
 
-class FCBlock_MultiDim(TimestepBlock):
-    """Parameter container, keys as reference FCBlock/FCBlock_MultiDim (openaimodel.py:2084-2141,2295-2332)."""
+class FCBlock_MultiDim(TimestepBlock, PackCache):
+    """FCBlock on a flattened [C, sdim, 1] feature (reference openaimodel.py:2084-2141, 2295-2332): GN32 -> SiLU ->
+    dense, + emb, GN32 -> SiLU -> dense, + skip(x).  Parameters keep the reference's keys / shapes (1x1 convs over
+    C*sdim "channels"); x is [B, sdim, 1, C] channels-last, optionally with a skip tensor concatenated on C."""
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_checkpoint=False):
         super().__init__()
@@ -340,15 +371,68 @@ class FCBlock_MultiDim(TimestepBlock):
                                         zero_module(nn.Conv2d(o_all, o_all, 1, padding=0)))
         self.skip_connection = nn.Identity() if o_all == c_all else nn.Conv2d(c_all, o_all, 1, padding=0)
 
-    def forward(self, x, emb, skip=None):
-        raise NotImplementedError("text-latent data flow (UNetModel0D data blocks) is not on the image sampling path")
+    def _pk(self):
+        cm, om = self.channels_multidim, self.out_channels_multidim
+        assert len(cm) == 3 and len(om) == 3 and cm[2] == 1 and om[2] == 1, "FCBlock_MultiDim expects [C, sdim, 1] features"
+        g1, c1, lin, g2, c2, sk = (self.in_layers[0], self.in_layers[2], self.emb_layers[1], self.out_layers[0],
+                                   self.out_layers[3], self.skip_connection)
+        tensors = [g1.weight, g1.bias, c1.weight, c1.bias, lin.weight, lin.bias, g2.weight, g2.bias, c2.weight, c2.bias]
+        if not isinstance(sk, nn.Identity):
+            tensors += [sk.weight, sk.bias]
+
+        def build():
+            d = dict(
+                g1=(_md_perm_vec(_h(g1.weight), cm), _md_perm_vec(_h(g1.bias), cm)),
+                w1=_md_perm(_h(c1.weight).view(self.out_channels, self.channels), om, cm), b1=_md_perm_vec(_h(c1.bias), om),
+                we=_md_perm(_h(lin.weight), om, [self.emb_channels]), be=_md_perm_vec(_h(lin.bias), om),
+                g2=(_md_perm_vec(_h(g2.weight), om), _md_perm_vec(_h(g2.bias), om)),
+                w2=_md_perm(_h(c2.weight).view(self.out_channels, self.out_channels), om, om), b2=_md_perm_vec(_h(c2.bias), om))
+            if not isinstance(sk, nn.Identity):
+                d["ws"] = _md_perm(_h(sk.weight).view(self.out_channels, self.channels), om, cm)
+                d["bs"] = _md_perm_vec(_h(sk.bias), om)
+            return d
+        return self._packed("fc", tuple(tensors), build)
+
+    def forward(self, x, emb_silu, skip=None, emb_out=None):
+        pk = self._pk()
+        cm, om = self.channels_multidim, self.out_channels_multidim
+        B, S = x.shape[0], x.shape[1]
+        x3 = x.reshape(B, S, x.shape[-1])
+        s3 = None if skip is None else skip.reshape(B, S, skip.shape[-1])
+        assert x3.shape[-1] + (0 if s3 is None else s3.shape[-1]) == cm[0] and S == cm[1]
+        g1w, g1b = pk["g1"]
+        h = ops.groupnorm0d_silu(x3, g1w.view(S, cm[0]), g1b.view(S, cm[0]), x1=s3, groups=32, eps=1e-5, silu=True)
+        e = ops.linear(emb_silu, pk["we"], pk["be"])                       # emb_layers: SiLU (already applied) -> Linear
+        h = ops.linear(h.view(B, -1), pk["w1"], pk["b1"], res=e)             # dense + emb_out
+        g2w, g2b = pk["g2"]
+        h = ops.groupnorm0d_silu(h.view(B, om[1], om[0]), g2w.view(om[1], om[0]), g2b.view(om[1], om[0]), groups=32,
+                                 eps=1e-5, silu=True)
+        xc = x3 if s3 is None else torch.cat([x3, s3], dim=-1)               # the reference's torch.cat (vd.py:371), 10-40 KB
+        if "ws" in pk:
+            r = ops.linear(xc.reshape(B, -1), pk["ws"], pk["bs"])
+        else:
+            r = xc.reshape(B, -1).contiguous()
+        y = ops.linear(h.view(B, -1), pk["w2"], pk["b2"], res=r)
+        return y.view(B, om[1], om[2], om[0])
+
+
+class OutputHead0D(nn.Sequential):
+    """normalization -> SiLU -> zero Linear_MultiDim (reference openaimodel.py:2953-2958): GroupNorm over the C channels
+    of the [C, sdim, 1] feature (per-channel affine: the regular GroupNorm kernel with HW = sdim)."""
+
+    def __init__(self, cur, output_channels):
+        super().__init__(GroupNorm(32, cur[0]), SiLU(), zero_module(Linear_MultiDim(cur, [output_channels], bias=True)))
+
+    def forward(self, x):
+        return self[2](self[0](x, silu=True))
 
 
 @register("openai_unet_0d_next")
 class UNetModel0D_Next(UNetModel2D_Next):
     """The 'text' diffuser of vd_four_flow: its *context* blocks (SpatialTransformers conditioned on CLIP text)
-    are what the image flow uses for text-to-image (vd.py:345 in the reference); its data blocks only hold
-    parameters here."""
+    are what the image flow uses for text-to-image (vd.py:345 in the reference); its data blocks (FCBlock_MultiDim /
+    Linear_MultiDim over [C, sdim, 1] features, held channels-last as [B, sdim, 1, C]) denoise the 768-d text latent of the
+    image-to-text / text-variation flows."""
 
     def __init__(self, input_channels, model_channels, output_channels, context_dim=788, num_noattn_blocks=(2, 2, 2, 2),
                  channel_mult=(1, 2, 4, 8), second_dim=(4, 4, 4, 4), with_attn=(True, True, True, False), num_heads=8,
@@ -410,12 +494,9 @@ class UNetModel0D_Next(UNetModel2D_Next):
                     self.add_context_layer(xattn(in_channels=cur[0], d_head=d_head, n_heads=n_heads))
             if level != 0:
                 self.add_data_layer(lin(cur, cur, bias=True))
-        if self.dlayer_included:
-            head = nn.Sequential(nn.GroupNorm(32, cur[0]), nn.SiLU(), zero_module(Linear_MultiDim(cur, [output_channels], bias=True)))
-        else:
-            head = None
+        head = OutputHead0D(cur, output_channels) if self.dlayer_included else None
         self.add_data_layer(head)
         self._finish_orders()
 
-    def forward(self, *a, **kw):
-        raise NotImplementedError("UNetModel0D_Next only contributes context blocks to the image sampling path")
+    def forward(self, x, timesteps, context):
+        raise NotImplementedError("the 0-D diffuser has no global layers of its own: call VD_v2_0.apply_model (x_type='text')")

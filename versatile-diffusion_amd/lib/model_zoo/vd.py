@@ -87,7 +87,7 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
             skip = None
         elif ltype == "c":
             h = run_context(h)
-    return ops.nhwc_to_nchw(h)
+    return h if h.dim() == 2 else ops.nhwc_to_nchw(h)   # 0-D (text-latent) data flow ends in [B, D]
 
 
 @register("vd_v2_0")

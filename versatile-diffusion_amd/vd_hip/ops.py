@@ -209,6 +209,17 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
     return out
 
 
+def groupnorm0d_silu(x, gamma_sc, beta_sc, *, x1=None, groups=32, eps=1e-5, silu=True):
+    """0-D data flow GroupNorm: x [B, S, C] (++ x1 on C), gamma_sc / beta_sc [S, C0+C1] -> [B, S, C0+C1]."""
+    _req(x, "x"); _req(x1, "x1"); _req(gamma_sc, "gamma"); _req(beta_sc, "beta")
+    B, S, c0 = x.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    out = torch.empty((B, S, c0 + c1), dtype=torch.float16, device=x.device)
+    _check(lib().vd_groupnorm0d_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma_sc), _ptr(beta_sc), _ptr(out), B, S, groups,
+                                         float(eps), 1 if silu else 0, _stream()))
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
     C = x.shape[-1]
