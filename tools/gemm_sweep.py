@@ -19,6 +19,7 @@ SHAPES = [  # (B, H, W, Cin, Cout, ksize)
     (8, 16, 16, 5120, 1280, 1), (8, 16, 16, 1280, 1280, 1), (8, 32, 32, 2560, 640, 1), (8, 64, 64, 1280, 320, 1),
     (8, 32, 32, 640, 640, 1), (8, 64, 64, 320, 320, 1), (8, 8, 8, 5120, 1280, 1),
     (8, 64, 64, 320, 960, 1), (8, 64, 64, 320, 640, 1), (8, 64, 64, 640, 640, 3),
+    (4, 512, 512, 128, 128, 3), (4, 256, 256, 256, 256, 3), (4, 128, 128, 512, 512, 3), (4, 512, 512, 256, 128, 3),
     (1, 64, 64, 4096, 4096, 1), (1, 64, 128, 8192, 8192, 1),
 ]
 SPLITS = [int(v) for v in os.environ.get("VD_SWEEP_SPLITS", "0,1,2,3,4,5,6,8,10,12,16").split(",")]

@@ -842,10 +842,10 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
                 const float t = model_us(c, ns);
                 if (t < best) { best = t; cfg = c.cfg; nsplit = ns; }
             }
-        // 256x128 block tiles (8 waves, one block per CU) move 25 % fewer bytes L2 -> LDS per FLOP, which is what bounds
-        // this kernel (tools/gemm_sweep.py: 8192^3 995 vs 895 TF/s); they only pay off once every CU gets several tiles
-        // (measured equal or slower on all UNet shapes, +10 % on the 512x512 VAE decoder convs)
-        if (d.split_k <= 0 && nsplit == 1 && d.N % 128 == 0 && (long)((d.M + 255) / 256) * (d.N / 128) * zb >= 1024) cfg = T256x128;
+        // (256x128 / 128x256 block tiles -- 25 % fewer bytes L2 -> LDS per FLOP, 8 waves, one block per CU -- reach 995 vs
+        //  895 TF/s at 8192^3 but measure equal on the VAE decoder's large convs (N = 128..512: the activation panel is
+        //  read by 1-4 column tiles only) and equal or slower on every UNet shape: kept for VD_GEMM_TILE=5|6 experiments,
+        //  never chosen here.)
     }
     {   // developer override for tile experiments: VD_GEMM_TILE=0|1|2 (never set in production runs)
         static const char* ov = getenv("VD_GEMM_TILE");
