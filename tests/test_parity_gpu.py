@@ -248,6 +248,28 @@ def test_ddim_full_latent_parity(full, dev, monkeypatch):
     assert rel_l2(z, zref) < LATENT_TOL
 
 
+def test_c1_geometry_ddim_parity(full, dev, monkeypatch):
+    """BASELINE configs[0] geometry (the reference's own CPU-runnable case): 1 prompt, 64x64x4 latent, L = 77, 10 guided
+    DDIM steps, full-width model -- final latent within the north-star bound of the fp32 path."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(21)
+    xT = torch.randn((1, 4, 64, 64), generator=g)
+    c = torch.randn((1, 77, 768), generator=g) * 0.5
+    u = torch.randn((1, 77, 768), generator=g) * 0.5
+    with torch.no_grad():
+        zref, _ = O.ddim_sample(sd, O.unet_plan(), sd["alphas_cumprod"], xT,
+                                [{"type": "text", "conditioning": c, "unconditional_conditioning": u}], 10, 7.5,
+                                global_ptr="image")
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.half().to(dev))
+    z, _ = DDIMSampler(net).sample(steps=10, shape=[1, 4, 64, 64], x_info={"type": "image"},
+                                   c_info={"type": "text", "conditioning": c.half().to(dev),
+                                           "unconditional_conditioning": u.half().to(dev),
+                                           "unconditional_guidance_scale": 7.5}, eta=0., verbose=False)
+    assert rel_l2(z, zref) < LATENT_TOL
+
+
 def test_full_clip_vs_oracle(dev):
     """CLIP ViT-L/14 towers at full size (427.6 M parameters per encoder object) against the CPU oracle."""
     from lib.model_zoo.clip import CLIPImageContextEncoder, CLIPTextContextEncoder
