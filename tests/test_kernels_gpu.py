@@ -302,6 +302,23 @@ def test_attention_fused_qkv_views_and_spike(ops, dev):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("D,gain", [(40, 3.0), (80, 3.0), (64, 4.0), (160, 2.5)])
+def test_attention_large_logits_and_descending_max(ops, dev, D, gain):
+    """Logits of +-40 and more (natural units): the running max rides in the MFMA C operand and P = exp2(s - m) must stay
+    finite in fp16 through the deferred-rescale window; keys are ordered so the row max first rises, then falls."""
+    B, N, H = 1, 640, 4
+    C = H * D
+    q = rnd((B, N, C), dev, gain, 60)
+    k = rnd((B, N, C), dev, gain, 61)
+    ramp = torch.cat([torch.linspace(0.2, 2.0, N // 2), torch.linspace(2.0, 0.05, N - N // 2)]).to(dev)
+    k = (k.float() * ramp[None, :, None]).half()
+    v = rnd((B, N, C), dev, 1.0, 62)
+    ref = _attn_ref(q, k, v, H, D ** -0.5, False)
+    out = ops.attention(q, k, v, H)
+    assert bool(torch.isfinite(out).all())
+    assert rel_l2(out, ref) < 5e-3
+
+
 def test_softmax_rows(ops, dev):
     s = torch.randn(300, 4096, device=dev) * 5
     ref = s.softmax(-1)
