@@ -799,9 +799,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     // once instead of 5x (94 FLOP per byte fetched vs 43 for 128x64) and M = 32768 gives exactly 256 blocks -- one
     // round, no tail: 90 -> 75 us on the 3x3 convs there.  No split-K, no GEGLU (odd number of 32-column blocks per wave).
     static const Cand cands[4] = {
-        {T128x128, 128, 128, 512, 0.75f, 1.10f, 0.50f, 1.00f, 5.f},
-        {T128x64, 128, 64, 768, 0.47f, 1.00f, 0.33f, 0.83f, 4.f},
-        {T64x64, 64, 64, 1024, 0.38f, 0.89f, 0.25f, 0.75f, 3.f},
+        {T128x128, 128, 128, 512, 0.75f, 1.10f, 0.50f, 1.00f, 6.5f},
+        {T128x64, 128, 64, 768, 0.50f, 1.00f, 0.25f, 0.83f, 4.f},
+        {T64x64, 64, 64, 1024, 0.38f, 0.78f, 0.25f, 0.75f, 3.f},
         {T128x320, 128, 320, 256, 1.20f, 1.50f, 0.50f, 1.00f, 6.f}};
     const int zb = d.batch;
     const bool can_split = (d.ws != nullptr || d.split_k > 1) && d.act != VD_ACT_GEGLU && !(d.flags & VD_EPI_OUT_F32);
