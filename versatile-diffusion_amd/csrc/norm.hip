@@ -13,6 +13,10 @@
 namespace {
 
 constexpr int GN_MAX_POS = 2;  // channel-chunk positions per thread: supports C <= 2*256*8 = 4096
+#ifndef VD_GN_U
+#define VD_GN_U 4
+#endif
+constexpr int GN_U = VD_GN_U;  // rows per trip of the slab loops = 16-byte loads in flight per thread
 
 struct GnGeom {
     int C, C8, TC, R, npos, rows_per_chunk, nchunk;
@@ -60,17 +64,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
             // 4 rows per trip, all four 16-byte loads issued before any is consumed: with ~2 blocks per CU a single
             // load in flight per thread left HBM at a quarter of its bandwidth (rows past the slab are clamped and
             // weighted 0 rather than branched around, so the loads stay unconditional)
-            for (int r = r0 + rl; r < r1; r += 4 * g.R) {
-                U4H8 t[4];
-                float wgt[4];
+            for (int r = r0 + rl; r < r1; r += GN_U * g.R) {
+                U4H8 t[GN_U];
+                float wgt[GN_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GN_U; ++u) {
                     const int ru = r + u * g.R;
                     wgt[u] = ru < r1 ? 1.f : 0.f;
                     t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (ru < r1 ? ru : r), cc * 8));
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < GN_U; ++u)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float v = (float)t[u].e[i] * wgt[u];
@@ -170,15 +174,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
     for (int pos = 0; pos < GN_MAX_POS; ++pos) {
         const int cc = tc + pos * g.TC;
         if (pos < g.npos && cc < g.C8) {
-            for (int r = r0 + rl; r < r1; r += 4 * g.R) {  // 4 loads in flight per thread, see gn_partial_kernel
-                U4H8 t[4];
+            for (int r = r0 + rl; r < r1; r += GN_U * g.R) {  // GN_U loads in flight per thread, see gn_partial_kernel (6 and 12 measured equal)
+                U4H8 t[GN_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GN_U; ++u) {
                     const int ru = r + u * g.R;
                     t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (ru < r1 ? ru : r), cc * 8));
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GN_U; ++u) {
                     const int ru = r + u * g.R;
                     U4H8 o;
 #pragma unroll
