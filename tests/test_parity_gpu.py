@@ -80,6 +80,24 @@ def test_tiny_text_latent_ddim_vs_oracle(tiny, dev):
     assert rel_l2(z, zr) < LATENT_TOL
 
 
+def test_guidance_replica_sharing_matches_explicit_batch(tiny, dev):
+    """apply_model*(x, repeat=2) == apply_model*([x; x]): the data blocks in front of the first context block run once per
+    sample instead of once per CFG replica; everything downstream sees the same tensors."""
+    g = load_gold("unet_tiny.npz")
+    x = T(g["x"], dev)[:1].repeat(2, 1, 1, 1)[:1]          # one sample
+    c2 = torch.cat([T(g["c_text"], dev)[:1] * 0.0, T(g["c_text"], dev)[:1]])   # [uncond; cond] contexts
+    t2 = torch.full((2,), 501, device=dev, dtype=torch.long)
+    ref = tiny.apply_model({"type": "image", "x": torch.cat([x, x])}, t2, {"type": "text", "c": c2})
+    out = tiny.apply_model({"type": "image", "x": x, "repeat": 2}, t2, {"type": "text", "c": c2})
+    assert out.shape == ref.shape == (2, 4, 16, 16)
+    assert rel_l2(out, ref) < 1e-3   # same kernels on the same values; GroupNorm's LDS atomics may reorder sums
+    ci = T(g["c_img"], dev)[:1]
+    specs = lambda: [{"type": "text", "c": c2, "ratio": 0.4}, {"type": "image", "c": torch.cat([ci * 0, ci]), "ratio": 0.6}]
+    ref = tiny.apply_model_multicontext({"type": "image", "x": torch.cat([x, x])}, t2, specs())
+    out = tiny.apply_model_multicontext({"type": "image", "x": x, "repeat": 2}, t2, specs())
+    assert rel_l2(out, ref) < 1e-3
+
+
 def test_tiny_ddim_vs_golden(tiny, dev, monkeypatch):
     from lib.model_zoo.ddim import DDIMSampler
     g = load_gold("ddim_tiny.npz")

@@ -150,8 +150,9 @@ class DDIMSampler(object):
         steps_dev = torch.from_numpy(np.ascontiguousarray(time_range).astype(np.int64)).to(dev)
 
         def body():
-            x_in = torch.cat([xs, xs]) if guided else xs
-            xi = {"type": x_info["type"], "x": x_in}
+            # guided: the UNet batch is [xs; xs] (ddim.py:144-149).  It is handed over as (xs, repeat=2) so the data blocks in
+            # front of the first context block run once (extension key of this package's apply_model*)
+            xi = {"type": x_info["type"], "x": xs, "repeat": 2 if guided else 1}
             if single:
                 eps = self.model.apply_model(xi, ts, c_info_list[0])
             else:

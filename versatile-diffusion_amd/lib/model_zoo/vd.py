@@ -35,11 +35,15 @@ class String_Reg_Buffer(nn.Module):
         return bytes(self.output_string.tolist()).decode()
 
 
-def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
+def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1):
     """Walk i/m/o orders of `data_net` (reference vd.py:352-378 / 429-453).
 
     ctx_specs: list of (context_blocks, context [B, L, Dc], ratio, kv_cache or None), one per context type.
-    x: NCHW latent; returns NCHW eps in fp16."""
+    x: NCHW latent; returns NCHW eps in fp16.
+    repeat > 1: the batch the reference would feed is `x` replicated `repeat` times ([x; x] of classifier-free guidance,
+    ddim.py:144-149) with identical timesteps per replica, while contexts / emb carry the full repeat * B rows.  The data
+    blocks in front of the first context block see identical inputs in every replica, so they run once on B rows and the
+    result (and the skip tensors saved so far) is replicated where the contexts make the replicas diverge."""
     d_iter = iter(enumerate(data_net.data_blocks))
     emb_outs = data_net.precompute_emb(emb_silu) if hasattr(data_net, "precompute_emb") else {}
     c_iters = [iter(spec[0]) for spec in ctx_specs]
@@ -69,14 +73,24 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention"):
         return out
 
     h = x
+    nb = x.shape[0]
+    shared = repeat > 1
     for ltype in data_net.i_order + data_net.m_order:
         if ltype == "d":
             di, blk = next(d_iter)
-            h = blk(h, emb_silu, None, emb_out=emb_outs.get(di))
+            eo = emb_outs.get(di)
+            if shared:
+                h = blk(h, emb_silu[:nb], None, emb_out=None if eo is None else eo[:nb])
+            else:
+                h = blk(h, emb_silu, None, emb_out=eo)
         elif ltype == "c":
+            if shared:  # the replicas diverge here
+                rep = lambda t: t.repeat(repeat, *([1] * (t.dim() - 1)))
+                h, hs, shared = rep(h), [rep(t) for t in hs], False
             h = run_context(h)
         elif ltype == "save_hidden_feature":
             hs.append(h)
+    assert not shared, "run_unet(repeat > 1) needs a context block in the input or middle stage"
     skip = None
     for ltype in data_net.o_order:
         if ltype == "load_hidden_feature":
@@ -230,7 +244,7 @@ class VD_v2_0(nn.Module):
         glayer_ptr = x_type if self.global_layer_ptr is None else self.global_layer_ptr
         emb = self._emb_silu(glayer_ptr, timesteps)
         spec = (self.diffuser[c_type].context_blocks, self._prep(c), 1.0, c_info.get("kv_cache"))
-        return run_unet(self.diffuser[x_type], [spec], self._prep(x), emb).to(x.dtype)
+        return run_unet(self.diffuser[x_type], [spec], self._prep(x), emb, repeat=int(x_info.get("repeat", 1))).to(x.dtype)
 
     @torch.no_grad()
     def apply_model_multicontext(self, x_info, timesteps, c_info_list, mixing_type="attention"):
@@ -240,4 +254,5 @@ class VD_v2_0(nn.Module):
         emb = self._emb_silu(x_type, timesteps)  # reference takes time_embed from diffuser[x_type] here (vd.py:415-417)
         specs = [(self.diffuser[ci["type"]].context_blocks, self._prep(ci["c"]), ci["ratio"], ci.get("kv_cache"))
                  for ci in c_info_list]
-        return run_unet(self.diffuser[x_type], specs, self._prep(x), emb, mixing_type).to(x.dtype)
+        return run_unet(self.diffuser[x_type], specs, self._prep(x), emb, mixing_type,
+                        repeat=int(x_info.get("repeat", 1))).to(x.dtype)
