@@ -214,7 +214,10 @@ def main():
                                "single text-context flow (vd_four_flow_v1-0 UNet 859.5M + text context blocks) + kl-f8 "
                                "decode; CLIP context encoding outside the timed region" % (args.ddim_steps, B),
                    "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": "batch-shard x%d" % world,
-                   "weights": "random-init (fan-in scaled normal), no checkpoints offline"},
+                   "weights": "random-init (fan-in scaled normal), no checkpoints offline",
+                   "exact_reuse": "context K/V projections computed once per sample() (inside the timed region); data blocks "
+                                  "in front of the first context block shared by the two CFG replicas; throughput is counted "
+                                  "on the reference's algorithmic FLOPs"},
     }
     if rank == 0:
         alg_tf = B * (2 * args.ddim_steps * UNET_GF_PER_SAMPLE + VAE_DECODE_GF) / 1e3
