@@ -201,8 +201,7 @@ class DDIMSampler(object):
         b = x.shape[0]
         nb = 2 * b if guided else b
         t_in = torch.full((nb,), step, device=x.device, dtype=torch.long)
-        x_in = torch.cat([x, x]) if guided else x
-        xi = {"type": x_info["type"], "x": x_in}
+        xi = {"type": x_info["type"], "x": x, "repeat": 2 if guided else 1}   # [x; x] of the reference, see _loop_static
         if single:
             eps = self.model.apply_model(xi, t_in, c_info_list[0])
         else:
