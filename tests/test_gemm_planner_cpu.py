@@ -1,0 +1,68 @@
+"""vd_gemm_plan (tile shape / split-K cost model) is host code: its decisions for the UNet's shapes are pinned here so a
+retune that silently changes them shows up in the CPU suite.  No GPU work is launched."""
+import ctypes
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+
+T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
+
+
+def plan(M, N, K, ks=1, B=8, ws=True, act=0):
+    from vd_hip.loader import VdGemmDesc, lib
+    d = VdGemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a0 = d.w = d.out = 16
+    if ks == 3:
+        h = int(round((M // B) ** 0.5))
+        d.Hin = d.Win = d.Hout = d.Wout = h
+        d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, K // 9
+    d.act = act
+    d.ws = 16 if ws else None
+    cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+    return cfg.value, ns.value
+
+
+def test_round_quantisation_drives_the_split():
+    # 160 tiles of 128x128: split 3 = 480 blocks (one round of 512 slots), not split 4 = 640 (two rounds)
+    assert plan(2048, 1280, 11520, ks=3) == (T128x128, 3)
+    assert plan(2048, 1280, 23040, ks=3) == (T128x128, 3)
+    # 320 tiles already cover most of a round: no split
+    assert plan(8192, 640, 5760, ks=3) == (T128x128, 1)
+    # 40 tiles at the 8x8 level: deep split
+    cfg, ns = plan(512, 1280, 11520, ks=3)
+    assert cfg in (T128x128, T128x64) and 5 <= ns <= 12
+
+
+def test_wide_tile_for_the_64x64_level():
+    for K, ks in ((2880, 3), (5760, 3), (320, 1), (1280, 1)):
+        assert plan(32768, 320, K, ks=ks) == (T128x320, 1)
+    assert plan(32768, 960, 320) == (T128x320, 1)
+    # 64 tiles of 128x320 would leave 3/4 of the CUs idle
+    assert plan(8192, 640, 5760, ks=3)[0] != T128x320
+
+
+def test_no_split_without_workspace_and_for_geglu():
+    assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
+    assert plan(32768, 2560, 320, act=1) == (T128x128w8, 1)   # VD_ACT_GEGLU = 1
+
+
+def test_small_m_weight_streaming_splits_k():
+    cfg, ns = plan(8, 5120, 5120)
+    assert cfg == T64x64 and ns >= 8
+    assert plan(8, 1280, 320) == (T64x64, 1)
+
+
+def test_plan_rejects_bad_descriptors():
+    from vd_hip.loader import VdGemmDesc, lib
+    d = VdGemmDesc()
+    d.M, d.N, d.K = 128, 128, 12   # K not a multiple of 8
+    d.a0 = d.w = d.out = 16
+    cfg, ns = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) != 0
+    assert b"multiple of 8" in lib().vd_last_error()
