@@ -31,7 +31,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define VD_HIP_ABI_VERSION 1
+#define VD_HIP_ABI_VERSION 2
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -40,6 +40,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VD_EPI_RESIDUAL 4     /* + res[m][n] after activation and alpha                       */
 #define VD_EPI_BIAS_ALONG_M 8 /* bias indexed by output row (V^T = Wv x^T in the VAE AttnBlock) */
 #define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
+#define VD_EPI_LNFOLD 32      /* A rows are LayerNorm'ed on the fly, see VdGemmDesc.colsum     */
 
 #define VD_ACT_NONE 0
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
@@ -49,6 +50,13 @@ typedef struct ihipStream_t* hipStream_t;
 /*
  * One fused GEMM / implicit-GEMM convolution:
  *    out[m][n] = ( act( sum_k A[m][k] W[n][k] + bias + rowvec ) ) * alpha + res[m][n]
+ * With VD_EPI_LNFOLD the A rows are layer-normalised over K on the fly:
+ *    LN(a)[m][k] = (a[m][k] - mean_m) * rstd_m * gamma[k] + beta[k]
+ *    sum_k LN(a)[m][k] W[n][k] = rstd_m * ( sum_k a[m][k] W'[n][k] - mean_m * colsum[n] ) + bias'[n]
+ * with W' = gamma (*) W (passed as `w`), colsum[n] = sum_k W'[n][k] (fp32) and bias' = beta W^T + bias (passed as `bias`),
+ * all prepared once per layer by the host; mean / rstd come from the A tiles as they pass through LDS, so the
+ * nn.LayerNorm in front of a projection (lib/model_zoo/attention.py:214-218) costs no pass over memory.
+ * Plain (non-conv, single-source) A only, no split-K.
  * A[m][k] is gathered on the fly: m -> (b, oy, ox) over Hout x Wout, k -> (ky, kx, c) with c running
  * over the channels of a0 (c0) then a1 (c1) -- i.e. torch.cat([a0, a1], dim=1) is never materialised --
  * at input pixel ((oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups) (ups=1: nearest 2x upsample
@@ -72,6 +80,9 @@ typedef struct VdGemmDesc {
     int32_t batch;       /* blockIdx.z batches with the element strides below                    */
     int32_t split_k;     /* 0 = heuristic                                                        */
     int64_t stride_a, stride_w, stride_out, stride_res;
+    const float* colsum; /* VD_EPI_LNFOLD: fp32 [N] row sums of w                                */
+    float ln_eps;        /* VD_EPI_LNFOLD: epsilon of the folded LayerNorm                       */
+    int32_t reserved;
 } VdGemmDesc;
 
 /* Replaces nn.Conv2d / nn.Linear / torch.bmm call sites:
@@ -81,10 +92,15 @@ typedef struct VdGemmDesc {
  *   HF CLIP linear layers reached from lib/model_zoo/clip.py:58-61,95-100 */
 int vd_gemm_f16(const VdGemmDesc* desc, hipStream_t stream);
 size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
-/* Dry run of the launch planner: tile_cfg 0 = 128x128, 1 = 128x64, 2 = 64x64, 3/4 = 8-wave 128x128 / 128x64 (GEGLU),
- * 5 = 256x128, 6 = 128x256, 7 = 128x320 block tile; nsplit = split-K factor.
- * Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
+/* Dry run of the launch planner: tile_cfg indexes the instantiation table of vd_gemm_config_name(); nsplit = split-K
+ * factor.  Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
 int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
+/* "gemm_f16_kernel<BM,BN,WM,WN,NT,STAGES,KB>" of tile_cfg (NULL when out of range); vd_gemm_num_configs() entries. */
+const char* vd_gemm_config_name(int tile_cfg);
+int vd_gemm_num_configs(void);
+/* Development hook (tools/gemm_sweep.py, A/B runs): force every following vd_gemm_f16 of this process onto tile_cfg
+ * (-1 = planner's choice) where the shape permits.  Process-global and unsynchronised: not for production use. */
+int vd_gemm_set_override(int tile_cfg);
 
 /* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
  * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().

@@ -24,7 +24,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(PROTOTYPES), (declared ^ set(PROTOTYPES))
     for name in declared:
         assert hasattr(h, name), name
-    assert h.vd_abi_version() == 1
+    assert h.vd_abi_version() == 2
     # argument validation works without a device
     from vd_hip.loader import VdGemmDesc
     d = VdGemmDesc()
@@ -35,8 +35,9 @@ def test_capi_exports_every_declared_symbol():
 
 def test_gemm_desc_struct_matches_header():
     from vd_hip.loader import VdGemmDesc
-    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8
+    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4
     assert VdGemmDesc.stride_a.offset == 8 * 8 + 24 * 4
+    assert VdGemmDesc.colsum.offset == 8 * 8 + 24 * 4 + 4 * 8   # LayerNorm-fold fields (ABI 2)
 
 
 def test_model_cfg_bank_resolves_four_flow():

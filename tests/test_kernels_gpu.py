@@ -145,6 +145,90 @@ def test_gemm_geglu(ops, dev):
     assert rel_l2(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,K,N,offset", [(4096, 320, 960, 0.0), (1000, 640, 640, 0.5), (256, 1280, 3840, -2.0), (130, 320, 320, 8.0),
+                                          (2048, 328, 192, 0.3)])
+def test_gemm_layernorm_fold(ops, dev, M, K, N, offset):
+    """VD_EPI_LNFOLD: LayerNorm(x) @ W^T + b with the LayerNorm folded into the projection (row statistics taken from
+    the A tiles inside the GEMM) vs nn.LayerNorm followed by the matmul in fp32.  `offset` shifts the row means away from
+    zero (the fold subtracts mean * colsum from the accumulator: the cancellation must stay harmless)."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    x = rnd((M, K), dev, 1.5, 50) + offset
+    w = rnd((N, K), dev, 0.05, 51)
+    b = rnd((N,), dev, 0.3, 52)
+    ln = torch.nn.LayerNorm(K, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(K, generator=torch.Generator().manual_seed(53)).to(dev))
+        ln.bias.copy_(0.2 * torch.randn(K, generator=torch.Generator().manual_seed(54)).to(dev))
+    res = rnd((M, N), dev, 1.0, 55)
+    ref = F.layer_norm(x.float(), (K,), ln.weight.float(), ln.bias.float(), 1e-5) @ w.float().t() + b.float() + res.float()
+    wp, bp, cs = fold_layernorm(w, b, ln)
+    out = ops.gemm(x, wp, bias=bp, res=res, colsum=cs, ln_eps=1e-5)
+    assert rel_l2(out, ref) < 3e-3
+    # without a bias on the projection (to_q / to_k / to_v): bias' = beta W^T alone
+    wp, bp, cs = fold_layernorm(w, None, ln)
+    out = ops.gemm(x, wp, bias=bp, colsum=cs, ln_eps=1e-5)
+    assert rel_l2(out, ref - b.float() - res.float()) < 3e-3
+
+
+def test_gemm_layernorm_fold_geglu(ops, dev):
+    from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.pack import pack_geglu
+    M, C = 1024, 320
+    x = rnd((M, C), dev, 1.0, 56) + 0.4
+    w = rnd((8 * C, C), dev, 0.05, 57)
+    b = rnd((8 * C,), dev, 0.2, 58)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=torch.Generator().manual_seed(59)).to(dev))
+        ln.bias.copy_(0.2 * torch.randn(C, generator=torch.Generator().manual_seed(60)).to(dev))
+    h = F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), 1e-5) @ w.float().t() + b.float()
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wf, bf, _ = fold_layernorm(w, b, ln)
+    wp, bp = pack_geglu(wf, bf)
+    out = ops.gemm(x, wp, bias=bp, act=ops.ACT_GEGLU, colsum=wp.float().sum(1).contiguous(), ln_eps=1e-5)
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_gemm_every_tile_configuration(ops, dev):
+    """Every instantiation of the GEMM template (vd_gemm_set_override) on a conv with concat + row vector, a plain GEMM
+    with ragged M / N / K and bias + residual, a split-K problem and a LayerNorm-folded projection."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.loader import lib
+    from vd_hip.pack import pack_conv_weight
+    B, H, W, c0, c1, Co = 2, 16, 16, 128, 64, 384
+    x0, x1 = rnd((B, H, W, c0), dev, 1.0, 61), rnd((B, H, W, c1), dev, 1.0, 62)
+    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.05, 63)
+    bias, rv = rnd((Co,), dev, 0.5, 64), rnd((B, Co), dev, 0.5, 65)
+    ref_conv = _conv_ref(torch.cat([x0, x1], -1), wt, bias, 1, 1, 0) + rv.float().view(B, 1, 1, Co)
+    a, w2 = rnd((1000, 200), dev, 1.0, 66), rnd((328, 200), dev, 0.05, 67)
+    b2, r2 = rnd((328,), dev, 0.5, 68), rnd((1000, 328), dev, 1.0, 69)
+    ref_plain = a.float() @ w2.float().t() + b2.float() + r2.float()
+    a3, w3 = rnd((256, 64 * 48), dev, 1.0, 70), rnd((320, 64 * 48), dev, 0.03, 71)
+    ref_split = a3.float() @ w3.float().t()
+    K = 640
+    xl, wl = rnd((700, K), dev, 1.2, 72) + 0.5, rnd((448, K), dev, 0.05, 73)
+    ln = torch.nn.LayerNorm(K, eps=1e-5).to(dev)
+    ref_ln = F.layer_norm(xl.float(), (K,), ln.weight.float(), ln.bias.float(), 1e-5) @ wl.float().t()
+    wlp, blp, cs = fold_layernorm(wl, None, ln)
+    n = lib().vd_gemm_num_configs()
+    assert n >= 8
+    try:
+        for cfg in range(n):
+            ops.gemm_set_override(cfg)
+            name = ops.gemm_kernel_name(cfg)
+            out = ops.conv2d_nhwc(x0, pack_conv_weight(wt), bias, x1=x1, rowvec=rv, rows_per_batch=H * W)
+            assert rel_l2(out, ref_conv) < 2e-3, name
+            out = ops.gemm(a, w2, bias=b2, res=r2)
+            assert rel_l2(out, ref_plain) < 2e-3, name
+            out = ops.gemm(a3, w3, split_k=3)
+            assert rel_l2(out, ref_split) < 2e-3, name
+            out = ops.gemm(xl, wlp, bias=blp, colsum=cs, ln_eps=1e-5)
+            assert rel_l2(out, ref_ln) < 3e-3, name
+    finally:
+        ops.gemm_set_override(-1)
+
+
 @pytest.mark.parametrize("split", [2, 5, 16, 32])
 def test_gemm_split_k(ops, dev, split):
     M, N, K = 192, 320, 64 * 40

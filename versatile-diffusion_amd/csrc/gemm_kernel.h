@@ -1,0 +1,711 @@
+// fp16 MFMA GEMM / implicit-GEMM convolution kernel template for gfx950 (CDNA4).  Included by gemm.hip (planner,
+// 2-waves-per-SIMD instances) and gemm_big.hip (one-wave-per-SIMD instances with large per-wave tiles).
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// A is never materialised for convolutions: the tile loader gathers the (kh,kw) tap of an NHWC activation (optionally
+// the channel-concatenation of two tensors, optionally nearest-2x upsampled, optionally strided) straight into LDS.
+// W is K-contiguous ([N][K], K ordered (kh, kw, cin)): torch Linear weights as they are, conv weights repacked once.
+//
+// Replaces on the reference path (all stock torch ops there):
+//   nn.Conv2d 3x3 / 1x1 in ResBlock, Up/Downsample, SpatialTransformer.proj_in/out
+//     (/root/reference/lib/model_zoo/openaimodel.py:89-117,133-159,254-274, attention.py:255-266)
+//   nn.Linear in CrossAttention / GEGLU FeedForward / time_embed / emb_layers (attention.py:37-64,170-193,
+//     openaimodel.py:2627-2633), nn.LayerNorm in front of them (attention.py:205-218) through VD_EPI_LNFOLD
+//   the VAE convs and AttnBlock bmm's (autokl_modules.py:82-202)
+//
+// Structure of a block (BM x BN output tile, NT/64 waves, wave tile WM x WN = MI x NI MFMA tiles of 32x32):
+//   * K is walked in KB-deep tiles through a ring of STAGES LDS buffers.  Tiles travel global -> LDS by LDS-DMA
+//     (buffer_load ... lds: no VGPR round trip, no ds_write); the XOR swizzle of the LDS image is applied on the source
+//     side.  A tile is issued STAGES-1 tiles ahead, in PIECES (one 1-KiB wave instruction each) that are spread between
+//     the MFMAs of the first k-steps of an iteration: issued in one burst they cost the wave 60-180 issue cycles apiece
+//     with the matrix pipe idle.
+//   * Operand fragments are double-buffered in registers and the pipeline runs ACROSS the per-tile barrier: the
+//     fragments of k-step 0 of tile i+1 are requested right after the barrier and the MFMAs of the last k-step of tile i
+//     are issued behind them, so the ds_read latency after a barrier is covered by matrix work.
+//   * v_mfma_f32_32x32x16_f16, fp32 accumulation, operands swapped (MFMA A operand = W rows, B operand = activation
+//     rows) so a lane owns ONE output row and 4 consecutive columns per register group: bias / LayerNorm fold /
+//     activation / GEGLU gating / alpha run in registers, the tile is staged through LDS and leaves as 16-byte row
+//     segments with the per-batch row vector and the residual added on the way out.
+//   * LDS bandwidth is the resource to economise (reads: (MI+NI)/(MI*NI) KiB per MFMA; DMA writes: (BM+BN)*KB*2 bytes
+//     per tile): hence the one-wave-per-SIMD instances with 64x160 / 64x128 wave tiles in gemm_big.hip.
+#pragma once
+#include "vd_common.h"
+#include "../../include/vd_hip.h"
+#include <atomic>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 64;  // the planner's K unit (halfs); kernels walk K in KB = 64 or 32
+
+struct GemmArgs {
+    VdGemmDesc d;
+    int tiles_m, tiles_n, kt_total, kt_per_split;
+    unsigned a0_bytes, a1_bytes, w_bytes;  // per-batch operand extents for the buffer descriptors (< 2^31)
+    int plain;                             // 1x1, stride 1, no pad / upsample, output grid == input grid
+};
+
+constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
+
+__device__ __forceinline__ void vd_store16_nt(void* p, uint4 v) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+}
+
+// swizzled byte offset of (row r, 16-byte slot s) inside a [rows][KB] f16 LDS tile.
+// KB = 64: 128-byte rows, 8 slots, key (r >> 1) & 7: the 16 rows of a ds_read_b128 lane group cover both halves of the
+//          256-byte bank row (r & 1) x 8 distinct keys.
+// KB = 32: 64-byte rows, 4 slots, key (r >> 2) & 3: rows 4a..4a+3 fill one bank row, a & 3 spreads the slot.
+template <int KB>
+__device__ __forceinline__ int lds_swz(int r) { return KB == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+template <int KB>
+__device__ __forceinline__ int lds_off_kb(int r, int s) { return r * (KB * 2) + ((s ^ lds_swz<KB>(r)) << 4); }
+
+struct EpiCtx {
+    const f16* bias;
+    const f16* rowvec;
+    const f16* res;
+    void* out;
+    int N, ldc, ldr, rows_per_batch, flags, act;
+    float alpha;
+};
+
+__device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
+    EpiCtx e;
+    e.bias = reinterpret_cast<const f16*>(d.bias);
+    e.rowvec = reinterpret_cast<const f16*>(d.rowvec);
+    e.res = reinterpret_cast<const f16*>(d.res) + (size_t)z * d.stride_res;
+    if (d.flags & VD_EPI_OUT_F32)
+        e.out = reinterpret_cast<float*>(d.out) + (size_t)z * d.stride_out;
+    else
+        e.out = reinterpret_cast<f16*>(d.out) + (size_t)z * d.stride_out;
+    e.N = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
+    e.ldc = d.ldc;
+    e.ldr = d.ldr;
+    e.rows_per_batch = d.rows_per_batch > 0 ? d.rows_per_batch : 1;
+    e.flags = d.flags;
+    e.act = d.act;
+    e.alpha = d.alpha;
+    return e;
+}
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    if (act == VD_ACT_QUICK_GELU) return vd_quick_gelu(v);
+    if (act == VD_ACT_SILU) return vd_silu(v);
+    return v;
+}
+
+// Second half of the epilogue for 8 consecutive output columns of one row (values already carry
+// bias / activation / alpha): + rowvec[batch] (+ residual) and the 16-byte store.
+__device__ __forceinline__ void epi_finish8(const EpiCtx& e, int row, int col, float* v) {
+    const bool full = (col + 8 <= e.N) && ((e.N & 7) == 0);
+    if (e.flags & VD_EPI_ROWVEC) {
+        const f16* rv = e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col;
+        if (full) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)t.e[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (col + i < e.N) v[i] += (float)rv[i];
+        }
+    }
+    if (e.flags & VD_EPI_RESIDUAL) {
+        const f16* rp = e.res + (size_t)row * e.ldr + col;
+        if (full && ((e.ldr & 7) == 0)) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(rp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)t.e[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (col + i < e.N) v[i] += (float)rp[i];
+        }
+    }
+    f16* op = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+    if (full && ((e.ldc & 7) == 0)) {
+        U4H8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t.e[i] = (f16)v[i];
+        *reinterpret_cast<uint4*>(op) = t.u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) op[i] = (f16)v[i];
+    }
+}
+
+// Full fp32 epilogue for 8 columns (split-K reduce kernel): bias, rowvec, act, alpha, residual, store.
+__device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, float* v) {
+    if (e.flags & VD_EPI_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) v[i] += (float)((e.flags & VD_EPI_BIAS_ALONG_M) ? e.bias[row] : e.bias[col + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = apply_act(e.act, v[i]) * e.alpha;
+    if (e.flags & VD_EPI_OUT_F32) {
+        float* op = reinterpret_cast<float*>(e.out) + (size_t)row * e.ldc + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (col + i < e.N) op[i] = v[i];
+        return;
+    }
+    epi_finish8(e, row, col, v);
+}
+
+// Epilogue part 2: the block's fp16 tile (LDS, [BM][CS_LD]) leaves as 16-byte row segments; CH = segments per row.
+// The residual OR the per-batch row vector of a segment (the usual case: a layer has one of them) is requested for ALL
+// of a thread's segments before the accumulators are staged (epi_prefetch), so that latency overlaps part 1; a layer
+// with both reads the row vector in line.
+template <int BM, int CH, int NT, int MAX_CH>
+__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int out_n0, int tid, uint4* pre) {
+    const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0);
+    const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
+    const bool want_rv = !want_res && (e.flags & VD_EPI_ROWVEC) != 0;
+#pragma unroll
+    for (int k = 0; k < MAX_CH; ++k) {
+        pre[k] = make_uint4(0, 0, 0, 0);
+        const int c = tid + k * NT;
+        if (vec_ok && c < BM * CH) {
+            const int r = c / CH, cc = (c % CH) * 8;
+            const int row = m0 + r, col = out_n0 + cc;
+            if (row < M && col + 8 <= e.N) {
+                if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
+                else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
+            }
+        }
+    }
+}
+
+template <int BM, int CH, int NT, int MAX_CH, int CS_LD>
+__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int out_n0, int tid, const f16* cs, const uint4* pre) {
+    const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
+    const bool both = (e.flags & VD_EPI_RESIDUAL) && (e.flags & VD_EPI_ROWVEC);
+#pragma unroll
+    for (int k = 0; k < MAX_CH; ++k) {
+        const int c = tid + k * NT;
+        if (c < BM * CH) {
+            const int r = c / CH, cc = (c % CH) * 8;
+            const int row = m0 + r, col = out_n0 + cc;
+            if (row < M && col < e.N) {
+                U4H8 t;
+                t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+                if (vec_ok && col + 8 <= e.N) {
+                    U4H8 a, b, o;
+                    a.u = pre[k];
+                    b.u = make_uint4(0, 0, 0, 0);
+                    if (both) b.u = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + (float)b.e[i]);
+                    // streaming output: non-temporal so 20..80 MB of results do not evict the weight / activation panels
+                    // that the other tiles of this XCD keep re-reading from its 4 MiB L2
+                    vd_store16_nt(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col, o.u);
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (float)t.e[i];
+                    epi_finish8(e, row, col, v);
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC>
+__global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
+    static_assert(KB == 64 || KB == 32, "K tile depth");
+    static_assert(STAGES >= 2, "LDS ring needs at least two stages");
+    constexpr int KROW_BYTES = KB * 2;  // one LDS row of a stage
+    constexpr int SLOTS = KB / 8;       // 16-byte slots per row == threads cooperating on a row
+    constexpr int KSUB = 64 / KB;       // kernel K tiles per planner K tile (the planner counts in 64s)
+    constexpr int KS = KB / 16;         // MFMA k-steps per tile (even: fragment set of step ks is ks & 1)
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    static_assert(WAVES_M * WAVES_N * 64 == NT, "waves must tile the block");
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int NMF = MI * NI;     // MFMAs per k-step and wave
+    constexpr int RPP = NT / SLOTS;  // rows staged per pass: SLOTS threads per row
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    constexpr int LPT = A_PASSES + B_PASSES;  // DMA pieces per thread and tile
+    constexpr int STAGE_BYTES = (BM + BN) * KROW_BYTES;
+    constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
+    constexpr int EPI_BYTES = BM * CS_LD * 2;
+    constexpr int D = STAGES - 1;  // prefetch distance in tiles
+    // the pieces of the tile issued in an iteration go into its first PSTEPS k-steps (the last step holds the wait)
+    constexpr int PSTEPS = KS > 2 ? KS - 2 : 1;
+    constexpr int PPS = (LPT + PSTEPS - 1) / PSTEPS;
+    static_assert(LPT * (D > 1 ? D - 1 : 1) < 64, "vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const VdGemmDesc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of
+    // logical tiles (n fastest) so neighbouring tiles that share the A row-panel share an L2.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int z = blockIdx.z;
+
+    // ---- operands are read through buffer descriptors: one SGPR base + per-lane 32-bit byte offset + a scalar
+    // K offset per tile.  Out-of-image taps, rows >= M / N and the ragged K tail simply use an out-of-range
+    // offset and the hardware returns zeros: no branches and (within a conv tap) no VALU work per K tile.
+    const i32x4 ws_a0 = make_rsrc_words(reinterpret_cast<const f16*>(d.a0) + (size_t)z * d.stride_a, p.a0_bytes);
+    const i32x4 ws_a1 = make_rsrc_words(d.a1 ? reinterpret_cast<const f16*>(d.a1) + (size_t)z * d.stride_a : d.a0,
+                                        d.a1 ? p.a1_bytes : 0u);
+    const i32x4 ws_w = make_rsrc_words(reinterpret_cast<const f16*>(d.w) + (size_t)z * d.stride_w, p.w_bytes);
+
+    // per-thread gather coordinates: SLOTS threads per LDS row, RPP rows per pass
+    const int lrow = tid / SLOTS, lslot = tid % SLOTS;
+    int a_iy0[A_PASSES], a_ix0[A_PASSES], a_pix[A_PASSES];
+    const int HWo = d.Hout * d.Wout;
+    const int Hv = d.Hin << d.ups, Wv = d.Win << d.ups;
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+        const int m = m0 + lrow + RPP * ps;
+        if (m < d.M && p.plain) {  // plain matrix / 1x1 stride-1 conv: output row == input pixel, no index division
+            a_iy0[ps] = 0;
+            a_ix0[ps] = 0;
+            a_pix[ps] = m;
+        } else if (m < d.M) {
+            const int b = m / HWo;
+            const int rem = m - b * HWo;
+            const int oy = rem / d.Wout;
+            const int ox = rem - oy * d.Wout;
+            a_iy0[ps] = oy * d.stride - d.pad;
+            a_ix0[ps] = ox * d.stride - d.pad;
+            a_pix[ps] = b * d.Hin * d.Win;
+        } else {
+            a_iy0[ps] = -(1 << 28);  // always out of bounds -> zero rows
+            a_ix0[ps] = 0;
+            a_pix[ps] = 0;
+        }
+    }
+
+    const int ctot = d.c0 + d.c1;
+    int kt_end = (split + 1) * p.kt_per_split;
+    if (kt_end > p.kt_total) kt_end = p.kt_total;
+    const int kt0 = split * p.kt_per_split * KSUB;  // in units of this kernel's K tile
+    const int nk = kt_end * KSUB - kt0;
+    const bool ragged = (d.K % BK) != 0;
+
+    // ---- LDS-DMA issue state.  The DMA destination is lane-linear (wave-uniform base + lane * 16), so the XOR swizzle
+    // of the LDS image is applied on the SOURCE side: the lane fetches the logical slot that lives at its physical slot.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned wave_dst = (unsigned)(__builtin_amdgcn_readfirstlane(wave) * 1024);  // one wave-wide DMA = 64 x 16 bytes
+    const int sw_slot = lslot ^ lds_swz<KB>(lrow);
+    unsigned dvoff_b[B_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+        const int n = n0 + lrow + RPP * ps;
+        dvoff_b[ps] = (n < d.N) ? (unsigned)((n * d.ldw + sw_slot * 8) * 2) : OOB_OFFSET;
+    }
+    unsigned dvoff_a[A_PASSES];
+    // (tap, channel offset) of the next tile to issue, advanced incrementally: no per-tile integer division
+    int n_tap = (kt0 * KB) / ctot;
+    int n_cc = kt0 * KB - n_tap * ctot;
+    int n_ky = n_tap / d.ksize, n_kx = n_tap - n_ky * d.ksize;
+    bool seg_dirty = true;
+    bool n_second = false;
+    // state of the tile being issued (wave-uniform)
+    i32x4 is_src = ws_a0;
+    unsigned is_soff_a = 0, is_soff_b = 0, is_dst_a = 0, is_dst_b = 0;
+    unsigned is_kmask = 0;  // 0x80000000 on lanes whose slot lies beyond a ragged K: pushes the offset out of range -> zeros
+    auto issue_begin = [&](int t, int buf) {
+        const bool second = n_cc >= d.c0;
+        if (second != n_second) { n_second = second; seg_dirty = true; }
+        if (seg_dirty) {  // wave-uniform: first tile, new tap, or switch to the concatenated source
+            seg_dirty = false;
+            const int ld = second ? d.lda1 : d.lda0;
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int iy = a_iy0[ps] + n_ky, ix = a_ix0[ps] + n_kx;
+                const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+                const int pix = a_pix[ps] + (iy >> d.ups) * d.Win + (ix >> d.ups);
+                dvoff_a[ps] = ok ? (unsigned)((pix * ld + sw_slot * 8) * 2) : OOB_OFFSET;
+            }
+        }
+        const int kglob = t * KB;
+        is_src = second ? ws_a1 : ws_a0;
+        is_soff_a = (unsigned)((second ? n_cc - d.c0 : n_cc) * 2);
+        is_soff_b = (unsigned)(kglob * 2);
+        is_dst_a = lds0 + (unsigned)(buf * STAGE_BYTES) + wave_dst;
+        is_dst_b = is_dst_a + BM * KROW_BYTES;
+        is_kmask = (ragged && (kglob + sw_slot * 8 >= d.K)) ? OOB_OFFSET : 0u;
+        n_cc += KB;  // advance to the next K tile
+        if (n_cc >= ctot) {
+            n_cc -= ctot;
+            ++n_tap;
+            ++n_kx;
+            if (n_kx == d.ksize) { n_kx = 0; ++n_ky; }
+            seg_dirty = true;
+        }
+    };
+    auto issue_piece = [&](int pc) {  // pc is a compile-time constant at every call site (unrolled loops)
+        if (pc < A_PASSES) {
+            dma16(is_src, is_dst_a + pc * RPP * KROW_BYTES, dvoff_a[pc < A_PASSES ? pc : 0] | is_kmask, is_soff_a);
+        } else {
+            const int q = pc - A_PASSES;
+            dma16(ws_w, is_dst_b + q * RPP * KROW_BYTES, dvoff_b[q < B_PASSES ? q : 0] | is_kmask, is_soff_b);
+        }
+    };
+
+    // acc[i][j] holds the TRANSPOSED 32x32 sub-tile (MFMA A operand = W rows, B operand = activation rows):
+    // lane owns output row m = l31 and, per register group g = r>>2, four consecutive columns n = 8g + 4hi + (r&3).
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS read offsets: the swizzle key is the same for every 32-row fragment of a lane, so each lane needs one offset
+    // per k-step and operand; fragments are immediate offsets (32 rows).
+    int rd_a[KS], rd_b[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        rd_a[ks] = lds_off_kb<KB>(wm * WM + l31, ks * 2 + hi);
+        rd_b[ks] = BM * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
+    }
+    f16x8 fa[2][MI], fb[2][NI];  // double-buffered operand fragments; indices are compile-time after unrolling
+    auto read_frags = [&](const char* st, int ks, f16x8* a, f16x8* b) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * KROW_BYTES);
+            a[i] = t.h;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(st + rd_b[ks] + j * 32 * KROW_BYTES);
+            b[j] = t.h;
+        }
+    };
+
+    // LayerNorm fold (VD_EPI_LNFOLD): row statistics of A are accumulated from the LDS-resident A tiles -- each thread
+    // re-reads the 16 bytes per pass it DMA'd itself -- so the consumer GEMM needs no separate LayerNorm pass at all.
+    const bool lnf = (d.flags & VD_EPI_LNFOLD) != 0;
+    float ln_s[A_PASSES], ln_q[A_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) ln_s[ps] = ln_q[ps] = 0.f;
+    auto ln_accumulate = [&](const char* st) {
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            union { uint4 u; f16x2 h2[4]; } t;
+            t.u = *reinterpret_cast<const uint4*>(st + ps * RPP * KROW_BYTES + tid * 16);
+            const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ln_s[ps] = __builtin_amdgcn_fdot2(t.h2[q], ones, ln_s[ps], false);
+                ln_q[ps] = __builtin_amdgcn_fdot2(t.h2[q], t.h2[q], ln_q[ps], false);
+            }
+        }
+    };
+
+    // one iteration = one K tile.  MODE 0: steady state (issues tile i + D, leaves D - 1 tiles in flight at the wait),
+    // MODE 1: drain (nothing left to issue), MODE 2: last tile (no successor to wait for).
+    auto iteration = [&](auto mode_tag, int i, int cbuf, int nbuf, int ibuf) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char* st = smem + cbuf * STAGE_BYTES;
+        if constexpr (MODE == 0) issue_begin(kt0 + i + D, ibuf);
+        if (lnf) ln_accumulate(st);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            // program order of a k-step is pinned with sched_barrier: fragment requests first, then the MFMAs with this
+            // step's DMA pieces in the gaps (hipcc otherwise emits the pieces as one burst behind the MFMAs -- the
+            // matrix pipe idles through it -- and sinks the post-barrier fragment requests behind the first MFMAs)
+            if (ks + 1 < KS) {
+                read_frags(st, ks + 1, fa[nxt], fb[nxt]);
+            } else if constexpr (MODE != 2) {
+                // tile i + 1 must have landed (own pieces), every wave must be done reading tile i - (STAGES - 2) ... i
+                if constexpr (MODE == 0) wait_vm<LPT * (D - 1)>();
+                else wait_vm<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
+                read_frags(smem + nbuf * STAGE_BYTES, 0, fa[nxt], fb[nxt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                if constexpr (MODE == 0) {
+                    if (ks < PSTEPS) {
+#pragma unroll
+                        for (int q = 0; q < PPS; ++q)
+                            if ((q * NMF) / PPS == m && ks * PPS + q < LPT) {
+                                issue_piece(ks * PPS + q);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                }
+                const int mi = m / NI, nj = m % NI;
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][nj], fa[cur][mi], acc[mi][nj], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the MFMAs of this step stay in front of the next step's wait / barrier
+        }
+    };
+
+    // ---- prologue: the first D tiles in one burst, then the fragments of k-step 0 of tile 0
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < nk) {
+                issue_begin(kt0 + j, j);
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
+            }
+        if (nk >= D) wait_vm<LPT * (D - 1)>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(smem, 0, fa[0], fb[0]);
+        int cbuf = 0, ibuf = D % STAGES;
+        int i = 0;
+        auto next = [](int b) { return b + 1 == STAGES ? 0 : b + 1; };
+        for (; i + D < nk; ++i) {
+            iteration(std::integral_constant<int, 0>{}, i, cbuf, next(cbuf), ibuf);
+            cbuf = next(cbuf);
+            ibuf = next(ibuf);
+        }
+        for (; i + 1 < nk; ++i) {
+            iteration(std::integral_constant<int, 1>{}, i, cbuf, next(cbuf), ibuf);
+            cbuf = next(cbuf);
+        }
+        iteration(std::integral_constant<int, 2>{}, i, cbuf, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
+
+    const EpiCtx e = make_epi(d, z);
+
+    // ---- split-K / fp32 output: straight from registers (4 consecutive floats per lane and group)
+    if (gridDim.y > 1 || (d.flags & VD_EPI_OUT_F32)) {
+        const bool partial = gridDim.y > 1;
+        float* base = partial ? d.ws + ((size_t)z * gridDim.y + split) * (size_t)d.M * d.N
+                              : reinterpret_cast<float*>(e.out);
+        const int ld = partial ? d.N : e.ldc;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + wm * WM + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * WN + j * 32 + 8 * g + 4 * hi;
+                    if (row < d.M && col < d.N) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                        if (!partial) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float t = v[q];
+                                if ((e.flags & VD_EPI_BIAS) && col + q < d.N)
+                                    t += (float)((e.flags & VD_EPI_BIAS_ALONG_M) ? e.bias[row] : e.bias[col + q]);
+                                v[q] = apply_act(e.act, t) * e.alpha;
+                            }
+                        }
+                        float* o = base + (size_t)row * ld + col;
+                        if (col + 4 <= d.N && (ld & 3) == 0) {
+                            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < d.N) o[q] = v[q];
+                        }
+                    }
+                }
+        }
+        return;
+    }
+
+    // ---- fused epilogue, part 1 (registers): (LayerNorm fold) + bias -> act / GEGLU -> * alpha -> fp16 into an LDS
+    // tile [BM][OUT_N]
+    f16* cs = reinterpret_cast<f16*>(smem);
+    const bool geglu = (d.act == VD_ACT_GEGLU);
+    const int out_n0 = geglu ? tn * (BN / 2) : n0;
+
+    // LayerNorm fold: mean / rstd per row of the block into LDS behind the epilogue tile
+    float2* lnst = reinterpret_cast<float2*>(smem + EPI_BYTES);
+    if (lnf) {
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            float s = ln_s[ps], q = ln_q[ps];
+#pragma unroll
+            for (int o = 1; o < SLOTS; o <<= 1) {
+                s += __shfl_xor(s, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (lslot == 0) {
+                const float inv_k = 1.0f / (float)d.K;
+                const float mean = s * inv_k;
+                float var = q * inv_k - mean * mean;
+                if (var < 0.f) var = 0.f;
+                lnst[lrow + RPP * ps] = make_float2(mean, rsqrtf(var + d.ln_eps));
+            }
+        }
+        __syncthreads();
+    }
+    const float* colsum = d.colsum;
+
+    // residual / row-vector segments of part 2 are requested NOW so their latency overlaps part 1 (the block is
+    // short-lived on the K = 320..1280 projections: every serial memory round trip shows)
+    constexpr int MAX_CH = BM * (BN / 8) / NT;
+    uint4 pre[MAX_CH];
+    if (geglu) epi_prefetch<BM, BN / 16, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre);
+    else epi_prefetch<BM, BN / 8, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int lrow_c = wm * WM + i * 32 + l31;
+        const int row = m0 + lrow_c;
+        float bm = 0.f;
+        if ((e.flags & VD_EPI_BIAS) && (e.flags & VD_EPI_BIAS_ALONG_M) && row < d.M) bm = (float)e.bias[row];
+        float ln_rstd = 1.f, ln_nmr = 0.f;  // y = rstd * acc - (mean * rstd) * colsum[n] + bias'[n]
+        if (lnf) {
+            const float2 st = lnst[lrow_c];
+            ln_rstd = st.y;
+            ln_nmr = -st.x * st.y;
+        }
+        if (geglu) {
+            if constexpr (NI == 2) {
+                // weight rows are packed per 64-row group as [32 value rows | 32 gate rows]: j = 0 value, j = 1 gate
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = wn * (WN / 2) + 8 * g + 4 * hi;     // column inside the block's output tile
+                    const int pn = n0 + wn * WN + 8 * g + 4 * hi;      // packed weight row of the value element
+                    U2H4 bv, bg, o;
+                    bv.u = make_uint2(0, 0);
+                    bg.u = make_uint2(0, 0);
+                    if (e.flags & VD_EPI_BIAS) {
+                        bv.u = *reinterpret_cast<const uint2*>(e.bias + pn);
+                        bg.u = *reinterpret_cast<const uint2*>(e.bias + pn + 32);
+                    }
+                    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), cg = cv;
+                    if (lnf) {
+                        cv = *reinterpret_cast<const float4*>(colsum + pn);
+                        cg = *reinterpret_cast<const float4*>(colsum + pn + 32);
+                    }
+                    const float cva[4] = {cv.x, cv.y, cv.z, cv.w}, cga[4] = {cg.x, cg.y, cg.z, cg.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(ln_rstd, acc[i][0][g * 4 + q], ln_nmr * cva[q]) + (float)bv.e[q];
+                        const float gt = fmaf(ln_rstd, acc[i][1][g * 4 + q], ln_nmr * cga[q]) + (float)bg.e[q];
+                        o.e[q] = (f16)(v * vd_gelu_erf(gt) * e.alpha);
+                    }
+                    *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lc = wn * WN + j * 32 + 8 * g + 4 * hi;
+                    const int col = n0 + lc;
+                    float bq[4] = {bm, bm, bm, bm};
+                    if ((e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M)) {
+                        if (col + 4 <= d.N && (d.N & 3) == 0) {
+                            U2H4 t;
+                            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < d.N) bq[q] = (float)e.bias[col + q];
+                        }
+                    }
+                    if (lnf) {
+                        if (col + 4 <= d.N) {
+                            const float4 c4 = *reinterpret_cast<const float4*>(colsum + col);
+                            bq[0] = fmaf(ln_nmr, c4.x, bq[0]);
+                            bq[1] = fmaf(ln_nmr, c4.y, bq[1]);
+                            bq[2] = fmaf(ln_nmr, c4.z, bq[2]);
+                            bq[3] = fmaf(ln_nmr, c4.w, bq[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < d.N) bq[q] = fmaf(ln_nmr, colsum[col + q], bq[q]);
+                        }
+                    }
+                    U2H4 o;
+                    if (e.act == VD_ACT_NONE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o.e[q] = (f16)(fmaf(ln_rstd, acc[i][j][g * 4 + q], bq[q]) * e.alpha);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o.e[q] = (f16)(apply_act(e.act, fmaf(ln_rstd, acc[i][j][g * 4 + q], bq[q])) * e.alpha);
+                    }
+                    *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
+    if (geglu) epi_writeout<BM, BN / 16, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre);
+    else epi_writeout<BM, BN / 8, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre);
+}
+
+template <int BM, int BN, int NT, int STAGES, int KB>
+constexpr int gemm_lds_bytes() {
+    constexpr int stage = (BM + BN) * KB * 2 * STAGES;
+    constexpr int epi = BM * (BN + 8) * 2 + BM * 8;  // epilogue tile + LayerNorm-fold row statistics
+    return stage > epi ? stage : epi;
+}
+
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC>
+int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
+    constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>();
+    static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
+    // the dynamic-LDS attribute is per device: one bit per device ordinal, set idempotently (safe under concurrent callers)
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            vd_set_error("vd_gemm_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+            return VD_ERR_LAUNCH;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC>), grid, dim3(NT), LDS, stream, a);
+    return vd_check_launch("vd_gemm_f16");
+}
+
+}  // namespace
+
+// one-wave-per-SIMD instances (gemm_big.hip); cfg = TileCfg value
+int vd_gemm_launch_big(int cfg, int variant, const void* args, int nsplit, hipStream_t stream);

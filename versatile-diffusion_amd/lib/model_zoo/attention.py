@@ -10,7 +10,8 @@ import torch.nn as nn
 
 from vd_hip import ops, pack
 
-from .hip_layers import Conv2d, GroupNorm, LayerNorm, Linear, PackCache, _h
+from . import hip_layers
+from .hip_layers import Conv2d, GroupNorm, LayerNorm, Linear, PackCache, _h, fold_layernorm
 
 
 class GEGLU(nn.Module, PackCache):
@@ -21,10 +22,20 @@ class GEGLU(nn.Module, PackCache):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
 
-    def forward(self, x):
-        wp, bp = self._packed("geglu", (self.proj.weight, self.proj.bias),
-                              lambda: pack.pack_geglu(_h(self.proj.weight), _h(self.proj.bias)))
-        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU)
+    def forward(self, x, ln=None):
+        """ln: the nn.LayerNorm the reference applies in front (x is then the UN-normalised input; folded, see
+        hip_layers.fold_layernorm)."""
+        if ln is None:
+            wp, bp = self._packed("geglu", (self.proj.weight, self.proj.bias),
+                                  lambda: pack.pack_geglu(_h(self.proj.weight), _h(self.proj.bias)))
+            return ops.linear(x, wp, bp, act=ops.ACT_GEGLU)
+
+        def build():
+            w, b, _ = fold_layernorm(_h(self.proj.weight), _h(self.proj.bias), ln)
+            wp, bp = pack.pack_geglu(w, b)
+            return wp, bp, wp.float().sum(1).contiguous()
+        wp, bp, cs = self._packed("geglu_ln", (self.proj.weight, self.proj.bias, ln.weight, ln.bias), build)
+        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=cs, ln_eps=ln.eps)
 
 
 class FeedForward(nn.Module):
@@ -35,8 +46,8 @@ class FeedForward(nn.Module):
         dim_out = dim if dim_out is None else dim_out
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), Linear(inner, dim_out))
 
-    def forward(self, x, res=None):
-        return self.net[2](self.net[0](x), res=res)
+    def forward(self, x, res=None, ln=None):
+        return self.net[2](self.net[0](x, ln=ln), res=res)
 
 
 class CrossAttention(nn.Module, PackCache):
@@ -67,16 +78,33 @@ class CrossAttention(nn.Module, PackCache):
         """[B, L, Dc] -> fused [B, L, 2*inner] (k | v); step-invariant for a fixed context."""
         return ops.linear(context, self._w_kv())
 
-    def forward(self, x, context=None, res=None, kv=None):
-        """x [B, N, C] -> to_out(attn) (+ res fused)."""
+    def _w_qkv_ln(self, ln):
+        return self._packed("qkv_ln", (self.to_q.weight, self.to_k.weight, self.to_v.weight, ln.weight, ln.bias),
+                            lambda: fold_layernorm(self._w_qkv(), None, ln))
+
+    def _w_q_ln(self, ln):
+        return self._packed("q_ln", (self.to_q.weight, ln.weight, ln.bias),
+                            lambda: fold_layernorm(_h(self.to_q.weight), None, ln))
+
+    def forward(self, x, context=None, res=None, kv=None, ln=None):
+        """x [B, N, C] -> to_out(attn) (+ res fused).  ln: the LayerNorm in front of the block's q (and self k / v)
+        projections, folded into them -- x is then the un-normalised input."""
         c = self.inner
         if context is None and kv is None:
-            qkv = ops.linear(x, self._w_qkv())
+            if ln is None:
+                qkv = ops.linear(x, self._w_qkv())
+            else:
+                w, b, cs = self._w_qkv_ln(ln)
+                qkv = ops.linear(x, w, b, colsum=cs, ln_eps=ln.eps)
             a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, scale=self.scale)
         else:
             if kv is None:
                 kv = self.project_context(context)
-            q = self.to_q(x)
+            if ln is None:
+                q = self.to_q(x)
+            else:
+                w, b, cs = self._w_q_ln(ln)
+                q = ops.linear(x, w, b, colsum=cs, ln_eps=ln.eps)
             a = ops.attention(q, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
         return self.to_out[0](a, res=res)
 
@@ -95,6 +123,10 @@ class BasicTransformerBlock(nn.Module):
         self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
 
     def forward(self, x, context=None, kv=None):
+        if hip_layers.LN_FOLD:  # the three LayerNorms ride in the q/k/v, q and GEGLU projections (VD_EPI_LNFOLD)
+            x = self.attn1(x, res=x, ln=self.norm1)
+            x = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2)
+            return self.ff(x, res=x, ln=self.norm3)
         x = self.attn1(self.norm1(x), res=x)
         x = self.attn2(self.norm2(x), context=context, res=x, kv=kv)
         x = self.ff(self.norm3(x), res=x)

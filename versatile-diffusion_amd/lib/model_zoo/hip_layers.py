@@ -6,10 +6,15 @@ the reference checkpoints -- but `forward` never touches a torch arithmetic op: 
 (cached, keyed on the parameter's storage/version) and enqueues vd_hip kernels.  Activations are fp16
 [B, H, W, C] (== (B*H*W, C) row-major) throughout; there is no CPU or eager fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from vd_hip import ops, pack
+
+# development switch: VD_LN_FOLD=0 runs every LayerNorm as its own kernel (A/B runs of the fold)
+LN_FOLD = os.environ.get("VD_LN_FOLD", "1") != "0"
 
 
 def _ver(t):
@@ -35,6 +40,23 @@ class PackCache:
 def _h(t):
     """fp16 contiguous device copy/view of a parameter (compute dtype of the path is fp16)."""
     return None if t is None else t.detach().to(torch.float16).contiguous()
+
+
+def fold_layernorm(w, b, ln):
+    """Fold `ln` (nn.LayerNorm in front of a projection) into the projection: LN(x) W^T + b =
+    rstd (x W'^T - mean colsum) + b'  with  W' = gamma (*) W,  colsum[n] = sum_k W'[n, k],  b' = beta W^T + b.
+    Returns (W' fp16, b' fp16, colsum fp32); vd_gemm_f16 (VD_EPI_LNFOLD) derives mean / rstd from the A tiles as they
+    pass through LDS, so the LayerNorm costs no pass over memory (reference attention.py:214-218 runs nn.LayerNorm as
+    its own op in front of attn1 / attn2 / ff).  colsum is taken over the fp16-ROUNDED folded weights -- exactly what the
+    MFMAs accumulate -- so the mean term cancels to fp32 round-off."""
+    g, be = ln.weight.detach().float(), ln.bias.detach().float()
+    wf = w.float()
+    wp = (wf * g[None, :]).to(torch.float16).contiguous()
+    colsum = wp.float().sum(1).contiguous()
+    bp = wf @ be
+    if b is not None:
+        bp = bp + b.float()
+    return wp, bp.to(torch.float16).contiguous(), colsum
 
 
 class Conv2d(nn.Conv2d, PackCache):

@@ -25,15 +25,20 @@ class VdGemmDesc(ctypes.Structure):
         ("alpha", ctypes.c_float), ("batch", ctypes.c_int32), ("split_k", ctypes.c_int32),
         ("stride_a", ctypes.c_int64), ("stride_w", ctypes.c_int64), ("stride_out", ctypes.c_int64),
         ("stride_res", ctypes.c_int64),
+        ("colsum", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
     ]
 
 
-# name -> (restype, argtypes); mirrors include/vd_hip.h one to one (checked by tests/test_capi_symbols.py)
+# name -> (restype, argtypes); mirrors include/vd_hip.h one to one (checked by
+# tests/test_host_cpu.py::test_capi_exports_every_declared_symbol)
 _P, _I, _F, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
 PROTOTYPES = {
     "vd_gemm_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P]),
     "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "vd_gemm_config_name": (ctypes.c_char_p, [_I]),
+    "vd_gemm_num_configs": (_I, []),
+    "vd_gemm_set_override": (_I, [_I]),
     "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),

@@ -11,7 +11,7 @@ import torch
 
 from .loader import VdGemmDesc, VdHipError, lib
 
-EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32 = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD = 1, 2, 4, 8, 16, 32
 ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3
 
 _ws_cache = {}
@@ -19,10 +19,18 @@ _ws_cache = {}
 # ---- optional per-launch instrumentation (bench.py roofline leg; off in the product path) -------------
 _prof = None
 PROFILE_SHAPES = False
-GEMM_KERNEL_NAMES = ("gemm_f16_kernel<128,128,64,64,256>", "gemm_f16_kernel<128,64,64,32,256>", "gemm_f16_kernel<64,64,32,32,256>",
-                     "gemm_f16_kernel<128,128,32,64,512>", "gemm_f16_kernel<128,64,32,32,512>",
-                     "gemm_f16_kernel<256,128,64,64,512>", "gemm_f16_kernel<128,256,64,64,512>",
-                     "gemm_f16_kernel<128,320,32,160,512>")
+
+
+def gemm_kernel_name(cfg):
+    """Instantiation name of a planner tile configuration (vd_gemm_config_name)."""
+    n = lib().vd_gemm_config_name(int(cfg))
+    return n.decode() if n else "gemm_f16_kernel<?>"
+
+
+def gemm_set_override(cfg):
+    """Development hook: force the GEMM tile configuration (-1 = planner)."""
+    _check(lib().vd_gemm_set_override(int(cfg)))
+
 
 
 def profile_begin():
@@ -99,12 +107,15 @@ def drop_workspaces(stream_id):
 
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
-         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None):
+         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
+    colsum (fp32 [N]) + ln_eps: the rows of A are layer-normalised on the fly (VD_EPI_LNFOLD); w / bias are then the
+    folded gamma (*) W and beta W^T + bias (hip_layers.fold_layernorm).
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
+    _req(colsum, "colsum", torch.float32)
     d = VdGemmDesc()
     if K is None:
         K = w.shape[-1]
@@ -139,6 +150,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         flags |= EPI_RESIDUAL
     if out_f32:
         flags |= EPI_OUT_F32
+    if colsum is not None:
+        flags |= EPI_LNFOLD
+        d.colsum, d.ln_eps = colsum.data_ptr(), float(ln_eps)
     d.flags, d.act, d.alpha = flags, int(act), float(alpha)
     d.batch, d.split_k = int(batch), int(split_k)
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = [int(s) for s in strides]
@@ -151,7 +165,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     # the workspace is sized for the split factor it will actually use
     name, d.ws = "gemm", None
     plan_cfg, plan_ns = ctypes.c_int(0), ctypes.c_int(1)
-    if act != ACT_GEGLU and not out_f32 and (split_k > 1 or (M * N <= 384 * 128 * 128 and K >= 1024)):
+    if act != ACT_GEGLU and not out_f32 and colsum is None and (split_k > 1 or (M * N <= 384 * 128 * 128 and K >= 1024)):
         d.ws = 1  # any non-null value: planning only
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         d.ws = None
@@ -160,7 +174,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             d.split_k = plan_ns.value
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
-        name = GEMM_KERNEL_NAMES[plan_cfg.value]
+        name = gemm_kernel_name(plan_cfg.value)
         if PROFILE_SHAPES:
             name += " M=%d N=%d K=%d ks=%d split=%d%s" % (M, N, K, d.ksize, plan_ns.value, " cat" if a1 is not None else "")
     nb = max(batch, 1)
