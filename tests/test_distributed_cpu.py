@@ -64,6 +64,13 @@ def test_batch_sharding_world2_gloo(tmp_path, B):
     assert torch.allclose(r0, single, atol=1e-5)
 
 
+def test_batch_smaller_than_world_raises_on_every_rank(tmp_path):
+    """B < world size is detected from the arguments on every rank (no rank is left hanging in the all_gather)."""
+    port = 29500 + (os.getpid() % 500) + 7
+    with pytest.raises(Exception, match="batch 1 < world size 2"):
+        mp.spawn(_worker, args=(2, port, 1, str(tmp_path)), nprocs=2, join=True)
+
+
 def test_shard_bounds():
     sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
     from lib.model_zoo.sharded import draw_initial_latent, shard_bounds

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
 
 T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
+T128x64d, T64x64d = 14, 15                                   # 3-stage ring for grids that do not fill the chip
+T128x128q, T128x128w8q, T128x320q = 16, 19, 20               # 32-deep K tiles, 4-stage ring (>= 20 K tiles per block)
 
 
 def plan(M, N, K, ks=1, B=8, ws=True, act=0):
@@ -33,28 +35,30 @@ def test_round_quantisation_drives_the_split():
     assert plan(2048, 1280, 11520, ks=3) == (T128x128, 3)
     assert plan(2048, 1280, 23040, ks=3) == (T128x128, 3)
     # 320 tiles already cover most of a round: no split
-    assert plan(8192, 640, 5760, ks=3) == (T128x128, 1)
+    assert plan(8192, 640, 5760, ks=3) == (T128x128q, 1)
     # 40 tiles at the 8x8 level: deep split
     cfg, ns = plan(512, 1280, 11520, ks=3)
-    assert cfg in (T128x128, T128x64) and 5 <= ns <= 12
+    assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
 
 
 def test_wide_tile_for_the_64x64_level():
-    for K, ks in ((2880, 3), (5760, 3), (320, 1), (1280, 1)):
-        assert plan(32768, 320, K, ks=ks) == (T128x320, 1)
+    for K, ks in ((2880, 3), (5760, 3), (1280, 1)):
+        assert plan(32768, 320, K, ks=ks) == (T128x320q, 1)   # >= 20 K tiles: deep ring of 32-deep tiles
+    assert plan(32768, 320, 320) == (T128x320, 1)             # 5 K tiles: 64-deep
     assert plan(32768, 960, 320) == (T128x320, 1)
     # 64 tiles of 128x320 would leave 3/4 of the CUs idle
-    assert plan(8192, 640, 5760, ks=3)[0] != T128x320
+    assert plan(8192, 640, 5760, ks=3)[0] not in (T128x320, T128x320q)
 
 
 def test_no_split_without_workspace_and_for_geglu():
     assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
-    assert plan(32768, 2560, 320, act=1) == (T128x128w8, 1)   # VD_ACT_GEGLU = 1
+    assert plan(32768, 2560, 320, act=1) == (T128x128w8q, 1)   # VD_ACT_GEGLU = 1
+    assert plan(512, 10240, 1280, act=1) == (T128x128w8, 1)
 
 
 def test_small_m_weight_streaming_splits_k():
     cfg, ns = plan(8, 5120, 5120)
-    assert cfg == T64x64 and ns >= 8
+    assert cfg in (T64x64, T64x64d) and ns >= 8
     assert plan(8, 1280, 320) == (T64x64, 1)
 
 

@@ -164,3 +164,41 @@ def test_product_package_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, fn)
+
+
+def test_registry_weight_sources_and_model_args(tmp_path, monkeypatch):
+    """get_model (reference common/get_model.py:19-87): a missing weight file raises unless the caller opts in, `pth` /
+    `ckpt` load, `backbone` / `layer_units` arguments are resolved before construction."""
+    import torch.nn as nn
+    from lib.cfg_helper import CfgDict
+    from lib.model_zoo import get_model
+    from lib.model_zoo.common.get_model import get_unit, preprocess_model_args, register
+    monkeypatch.delenv("VD_ALLOW_MISSING_WEIGHTS", raising=False)
+    m = meta()
+    cfg = CfgDict(type="autoencoderkl", args=m["vae"], pth=str(tmp_path / "nope.pth"))
+    with pytest.raises(FileNotFoundError, match="nope.pth"):
+        get_model()(cfg, verbose=False)
+    cfg.allow_missing_weights = True
+    net = get_model()(cfg, verbose=False)
+    monkeypatch.setenv("VD_ALLOW_MISSING_WEIGHTS", "1")
+    cfg.pop("allow_missing_weights")
+    get_model()(cfg, verbose=False)
+    # ckpt: {'state_dict': ...}
+    path = str(tmp_path / "kl.ckpt")
+    sd = {k: v + 1 for k, v in net.state_dict().items()}
+    torch.save({"state_dict": sd}, path)
+    net2 = get_model()(CfgDict(type="autoencoderkl", args=m["vae"], ckpt=path), verbose=False)
+    assert all(torch.equal(v, sd[k]) for k, v in net2.state_dict().items())
+
+    @register("_test_wrapper")
+    class Wrapper(nn.Module):
+        def __init__(self, backbone, layer_units):
+            super().__init__()
+            self.backbone = backbone
+            self.act = layer_units[0]()
+
+    w = get_model()(CfgDict(type="_test_wrapper", args=CfgDict(
+        backbone=CfgDict(type="autoencoderkl", args=m["vae"]), layer_units=["lrelu(negative_slope=0.2)", "none"])), verbose=False)
+    assert type(w.backbone).__name__ == "AutoencoderKL" and w.act.negative_slope == 0.2
+    assert get_unit()("conv(kernel_size=(3,3), padding=1)")(4, 8).kernel_size == (3, 3)
+    assert preprocess_model_args({"a": 1}) == {"a": 1}

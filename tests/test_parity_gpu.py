@@ -460,3 +460,126 @@ def test_full_text_latent_flow_vs_oracle(dev):
     e = net.apply_model({"type": "text", "x": x.half().to(dev)}, t.to(dev), {"type": "image", "c": c.half().to(dev)})
     assert e.shape == (2, 768)
     assert rel_l2(e, ref) < FWD_TOL
+
+
+# ---- round 2: coverage gaps named by the round-1 review ------------------------------------------------------------
+
+def test_full_schedule_50_step_ddim_parity(full, dev, monkeypatch):
+    """The north-star bound over the FULL schedule the bench runs: 50 guided DDIM steps (CFG 7.5) replayed from the HIP
+    graph, full-width model, 32x32 latent, B = 1 -- final latent within 1e-2 rel-L2 of the fp32 CPU path, so the error
+    growth over 50 replays is measured, not extrapolated from the 5 / 10 step tests."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(31)
+    xT = torch.randn((1, 4, 32, 32), generator=g)
+    c = torch.randn((1, 77, 768), generator=g) * 0.5
+    u = torch.randn((1, 77, 768), generator=g) * 0.5
+    with torch.no_grad():
+        zref, _ = O.ddim_sample(sd, O.unet_plan(), sd["alphas_cumprod"], xT,
+                                [{"type": "text", "conditioning": c, "unconditional_conditioning": u}], 50, 7.5,
+                                global_ptr="image")
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.half().to(dev))
+    z, _ = DDIMSampler(net).sample(steps=50, shape=[1, 4, 32, 32], x_info={"type": "image"},
+                                   c_info={"type": "text", "conditioning": c.half().to(dev),
+                                           "unconditional_conditioning": u.half().to(dev),
+                                           "unconditional_guidance_scale": 7.5}, eta=0., verbose=False)
+    err = rel_l2(z, zref)
+    print("50-step DDIM rel-L2 vs fp32 oracle: %.3e" % err)
+    assert err < LATENT_TOL
+
+
+def test_c3_shape_forward_vs_oracle(full, dev):
+    """BASELINE configs[2] geometry (image variation, bs = 8): CFG batch 16, 64x64 latent, image context L = 257 with the
+    all-zero unconditional half (app.py:345) -- full-width forward against the oracle."""
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn((16, 4, 64, 64), generator=g)
+    c = torch.randn((16, 257, 768), generator=g) * 0.5
+    c[:8] = 0
+    t = torch.tensor([981] * 4 + [601] * 4 + [201] * 4 + [1] * 4)
+    with torch.no_grad():
+        ref = O.apply_model(sd, O.unet_plan(), x, t, c, c_type="image", global_ptr="image")
+    e = net.apply_model({"type": "image", "x": x.half().to(dev)}, t.to(dev), {"type": "image", "c": c.half().to(dev)})
+    assert e.shape == (16, 4, 64, 64)
+    assert rel_l2(e, ref) < FWD_TOL
+
+
+def test_i2i_partial_schedule_vs_oracle(full, dev):
+    """Image variation with fidelity (app.py:355-371, ddim.py:97-103): x0 -> q_sample(ts[k]) -> the first k of 10 DDIM
+    steps, guided by an image context, full-width model -- against O.q_sample + O.ddim_sample(forward_steps=k)."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(33)
+    x0 = torch.randn((1, 4, 32, 32), generator=g) * 0.8
+    nz = torch.randn((1, 4, 32, 32), generator=g)
+    c = torch.randn((1, 257, 768), generator=g) * 0.5
+    u = torch.zeros_like(c)
+    steps, k = 10, 4
+    sched = O.ddim_schedule(sd["alphas_cumprod"], steps, 0.0)
+    ts = torch.full((1,), int(sched["timesteps"][k]), dtype=torch.long)
+    with torch.no_grad():
+        xk = O.q_sample(sd, x0, ts, nz)
+        zref, _ = O.ddim_sample(sd, O.unet_plan(), sd["alphas_cumprod"], xk,
+                                [{"type": "image", "conditioning": c, "unconditional_conditioning": u}], steps, 7.5,
+                                global_ptr="image", forward_steps=k)
+    z, _ = DDIMSampler(net).sample(steps=steps, shape=[1, 4, 32, 32],
+                                   x_info={"type": "image", "x0": x0.half().to(dev), "x0_forward_timesteps": k,
+                                           "x0_noise": nz.half().to(dev)},
+                                   c_info={"type": "image", "conditioning": c.half().to(dev),
+                                           "unconditional_conditioning": u.half().to(dev),
+                                           "unconditional_guidance_scale": 7.5}, eta=0., verbose=False)
+    assert rel_l2(z, zref) < LATENT_TOL
+
+
+def test_stochastic_ddim_with_injected_noise_vs_oracle(tiny, dev, monkeypatch):
+    """eta = 0.6: the per-step noise the sampler draws (torch.randn_like on the latent, like the reference's noise_like)
+    is injected, and the same tensors drive O.p_sample_ddim(noise=...) -- values, not just finiteness."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import synth, vd_oracle as O
+    m = meta()
+    gold = load_gold("ddim_tiny.npz")
+    sd = synth.synth_state_dict(synth.shapes_of(tiny), m["seed"])
+    sd.update(O.register_schedule())
+    steps, eta, scale = 5, 0.6, 3.0
+    g = torch.Generator().manual_seed(34)
+    noises = [torch.randn((2, 4, 16, 16), generator=g) for _ in range(steps)]
+    xT, c, u = torch.from_numpy(gold["xT"]), torch.from_numpy(gold["c_text"]), torch.from_numpy(gold["u_text"])
+    plan = O.unet_plan(**m["unet2d"])
+    sched = O.ddim_schedule(sd["alphas_cumprod"], steps, eta)
+    x = xT
+    with torch.no_grad():
+        for i, step in enumerate(np.flip(sched["timesteps"])):
+            index = steps - i - 1
+            x, _ = O.p_sample_ddim(sd, plan, sched, x, [{"type": "text", "conditioning": c, "unconditional_conditioning": u}],
+                                   index, step, scale, global_ptr="image", noise=noises[i].half().float())
+    it = iter(noises)
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: next(it).to(device=t.device, dtype=t.dtype))
+    z, _ = DDIMSampler(tiny).sample(steps=steps, shape=[2, 4, 16, 16], x_info={"type": "image", "xt": T(gold["xT"], dev)},
+                                    c_info={"type": "text", "conditioning": T(gold["c_text"], dev),
+                                            "unconditional_conditioning": T(gold["u_text"], dev),
+                                            "unconditional_guidance_scale": scale}, eta=eta, verbose=False)
+    assert rel_l2(z, x) < LATENT_TOL
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_sampler_rng_consumption_matches_reference(tiny, dev, eta):
+    """RNG contract (reference ddim.py:105 and :167): one latent-shaped torch.randn for x_T, then one
+    noise_like(x) = torch.randn_like(x) per step EVEN at sigma = 0.  After sample() the device generator must be where
+    the reference leaves it, so callers that keep drawing from it stay on the reference's stream."""
+    from lib.model_zoo.ddim import DDIMSampler
+    gold = load_gold("ddim_tiny.npz")
+    steps, shape = 6, [2, 4, 16, 16]
+    ct = {"type": "text", "conditioning": T(gold["c_text"], dev), "unconditional_conditioning": T(gold["u_text"], dev),
+          "unconditional_guidance_scale": 7.5}
+    torch.manual_seed(77)
+    DDIMSampler(tiny).sample(steps=steps, shape=shape, x_info={"type": "image"}, c_info=dict(ct), eta=eta, verbose=False)
+    after = torch.randn(8, device=dev)
+    torch.manual_seed(77)
+    x = torch.randn(shape, device=dev, dtype=torch.float16)     # ddim.py:105: randn(shape, device, dtype of the context)
+    for _ in range(steps):
+        torch.randn_like(x)                                       # ddim.py:167
+    expect = torch.randn(8, device=dev)
+    assert torch.equal(after, expect)

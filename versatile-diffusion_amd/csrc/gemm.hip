@@ -64,7 +64,9 @@ namespace {
 enum TileCfg {
     T128x128 = 0, T128x64 = 1, T64x64 = 2, T128x128w8 = 3, T128x64w8 = 4, T256x128 = 5, T128x256 = 6, T128x320 = 7,
     T128x320b = 8, T128x256b = 9, T256x128b = 10, T128x160 = 11, T128x320b32 = 12, T128x128d = 13, T128x64d = 14, T64x64d = 15,
-    T_COUNT = 16
+    // 32-deep K tiles, 4-stage ring (same LDS footprint as 64-deep / 2 stages, tiles issued 3 ahead instead of 1)
+    T128x128q = 16, T128x64q = 17, T64x64q = 18, T128x128w8q = 19, T128x320q = 20, T128x160q = 21,
+    T_COUNT = 22
 };
 struct CfgInfo { int bm, bn; const char* name; };
 const CfgInfo kCfg[T_COUNT] = {
@@ -75,7 +77,10 @@ const CfgInfo kCfg[T_COUNT] = {
     {128, 320, "gemm_f16_kernel<128,320,64,160,256,2,64>"},  {128, 256, "gemm_f16_kernel<128,256,64,128,256,3,64>"},
     {256, 128, "gemm_f16_kernel<256,128,128,64,256,3,64>"},  {128, 160, "gemm_f16_kernel<128,160,32,160,256,2,64>"},
     {128, 320, "gemm_f16_kernel<128,320,64,160,256,4,32>"},  {128, 128, "gemm_f16_kernel<128,128,64,64,256,3,64>"},
-    {128, 64, "gemm_f16_kernel<128,64,64,32,256,3,64>"},     {64, 64, "gemm_f16_kernel<64,64,32,32,256,3,64>"}};
+    {128, 64, "gemm_f16_kernel<128,64,64,32,256,3,64>"},     {64, 64, "gemm_f16_kernel<64,64,32,32,256,3,64>"},
+    {128, 128, "gemm_f16_kernel<128,128,64,64,256,4,32>"},   {128, 64, "gemm_f16_kernel<128,64,64,32,256,4,32>"},
+    {64, 64, "gemm_f16_kernel<64,64,32,32,256,4,32>"},       {128, 128, "gemm_f16_kernel<128,128,32,64,512,4,32>"},
+    {128, 320, "gemm_f16_kernel<128,320,32,160,512,4,32>"},  {128, 160, "gemm_f16_kernel<128,160,32,160,256,4,32>"}};
 
 std::atomic<int> g_override{-1};
 
@@ -195,14 +200,17 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         static const char* ov_env = getenv("VD_GEMM_TILE");
         int ov = g_override.load(std::memory_order_relaxed);
         if (ov < 0 && ov_env) ov = atoi(ov_env);
-        const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T256x128 || ov == T128x256 || ov == T128x256b || ov == T128x128d;
+        const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T256x128 || ov == T128x256 || ov == T128x256b || ov == T128x128d ||
+                              ov == T128x128q || ov == T128x128w8q;
         if (ov >= 0 && ov < T_COUNT && (d.act != VD_ACT_GEGLU || geglu_ok) && !(d.M < 96 || d.N < 96)) {
             cfg = (TileCfg)ov;
             // re-plan the split for the forced tile: fill the chip once (one block per CU for the 1-block-per-CU tiles)
             nsplit = 1;
             if (d.split_k <= 0 && can_split && a.kt_total >= 32) {
                 const int tiles = ((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * zb;
-                const int slots = (cfg == T128x128 || cfg == T128x128d) ? 512 : (cfg == T128x64 || cfg == T128x64d) ? 768 : (cfg == T64x64 || cfg == T64x64d) ? 1024 : 256;
+                const int slots = (cfg == T128x128 || cfg == T128x128d || cfg == T128x128q) ? 512
+                                  : (cfg == T128x64 || cfg == T128x64d || cfg == T128x64q) ? 768
+                                  : (cfg == T64x64 || cfg == T64x64d || cfg == T64x64q) ? 1024 : 256;
                 nsplit = slots / tiles;
                 if (nsplit < 1) nsplit = 1;
                 if (nsplit > VD_MAX_SPLIT_K / 2) nsplit = VD_MAX_SPLIT_K / 2;
@@ -211,6 +219,38 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         }
     }
     if (d.split_k > 0) nsplit = d.split_k;
+    if (nsplit > a.kt_total) nsplit = a.kt_total;
+    if (g_override.load(std::memory_order_relaxed) < 0) {
+        // Pipeline-depth variants of the chosen tile.  32-deep K tiles in a 4-stage ring (same LDS footprint as 64-deep
+        // x 2, tiles issued 3 ahead instead of 1) win wherever a block streams >= ~20 K tiles: inside a UNet forward the
+        // weights of every layer come from HBM (1.7 GB per forward against 256 MB of Infinity Cache) and one 64-deep tile
+        // of lead does not cover that latency (measured in-forward: 128x128 convs of the 32x32 level -14 %, 128x320
+        // -4..9 %, GEGLU -3..5 %; split-K shapes and the small tiles lose 3-10 % and keep 64-deep tiles).
+        // VD_GEMM_VARIANT=0 switches it off, =q forces it, =h additionally runs the N = 320 layers on two 128x160 blocks
+        // per CU (development A/B runs).
+        static const char* var_env = getenv("VD_GEMM_VARIANT");
+        const char v = var_env ? var_env[0] : 'a';
+        const int ktps = (a.kt_total + nsplit - 1) / nsplit;
+        const bool deep_k = ktps >= 20 && nsplit == 1;
+        if (v == 'h' && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
+        if (v == 'q' || (v != '0' && (cfg == T128x128w8 ? d.M >= 2048 : deep_k))) {
+            switch (cfg) {
+                case T128x128: cfg = T128x128q; break;
+                case T128x128w8: cfg = T128x128w8q; break;
+                case T128x320: cfg = T128x320q; break;
+                case T128x160: cfg = T128x160q; break;
+                case T128x64: if (v == 'q') cfg = T128x64q; break;
+                case T64x64: if (v == 'q') cfg = T64x64q; break;
+                default: break;
+            }
+        }
+        // grids that cannot fill the CUs twice over are latency-bound per block: those get a deeper ring of 64-deep tiles
+        const long grid_blocks = (long)((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * nsplit * zb;
+        if (grid_blocks <= 400 && ktps >= 8) {
+            if (cfg == T128x64) cfg = T128x64d;
+            else if (cfg == T64x64) cfg = T64x64d;
+        }
+    }
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     a.tiles_m = (d.M + bm - 1) / bm;
     a.tiles_n = (d.N + bn - 1) / bn;
@@ -254,12 +294,8 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     if (rc != VD_OK) return rc;
     const VdGemmDesc& d = a.d;
     const int zb = d.batch;
-    // grids that cannot fill the CUs twice over are latency-bound per block: those get a deeper DMA ring
-    const int grid_blocks = a.tiles_m * a.tiles_n * nsplit * zb;
-    if (grid_blocks <= 400 && a.kt_per_split >= 8 && g_override.load(std::memory_order_relaxed) < 0) {
-        if (cfg == T128x64) cfg = T128x64d;
-        else if (cfg == T64x64) cfg = T64x64d;
-    }
+    static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
+    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
     switch (cfg) {
         case T128x128: rc = launch_cfg<128, 128, 64, 64, 256, 2, 64, 2>(a, nsplit, stream); break;
         case T128x64: rc = launch_cfg<128, 64, 64, 32, 256, 2, 64, 2>(a, nsplit, stream); break;
@@ -273,6 +309,12 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         case T128x128d: rc = launch_cfg<128, 128, 64, 64, 256, 3, 64, 1>(a, nsplit, stream); break;
         case T128x64d: rc = launch_cfg<128, 64, 64, 32, 256, 3, 64, 2>(a, nsplit, stream); break;
         case T64x64d: rc = launch_cfg<64, 64, 32, 32, 256, 3, 64, 2>(a, nsplit, stream); break;
+        case T128x128q: rc = launch_cfg<128, 128, 64, 64, 256, 4, 32, 2>(a, nsplit, stream); break;
+        case T128x64q: rc = launch_cfg<128, 64, 64, 32, 256, 4, 32, 2>(a, nsplit, stream); break;
+        case T64x64q: rc = launch_cfg<64, 64, 32, 32, 256, 4, 32, 2>(a, nsplit, stream); break;
+        case T128x128w8q: rc = launch_cfg<128, 128, 32, 64, 512, 4, 32, 4>(a, nsplit, stream); break;
+        case T128x320q: rc = launch_cfg<128, 320, 32, 160, 512, 4, 32, 2>(a, nsplit, stream); break;
+        case T128x160q: rc = launch_cfg<128, 160, 32, 160, 256, 4, 32, 2>(a, nsplit, stream); break;
         default: rc = vd_gemm_launch_big(cfg, 0, &a, nsplit, stream); break;
     }
     if (rc != VD_OK) return rc;

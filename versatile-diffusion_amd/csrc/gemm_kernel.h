@@ -45,6 +45,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, kt_total, kt_per_split;
     unsigned a0_bytes, a1_bytes, w_bytes;  // per-batch operand extents for the buffer descriptors (< 2^31)
     int plain;                             // 1x1, stride 1, no pad / upsample, output grid == input grid
+    int nt_store;                          // non-temporal output stores (streaming results that nobody re-reads soon)
 };
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
@@ -185,7 +186,8 @@ __device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int
 }
 
 template <int BM, int CH, int NT, int MAX_CH, int CS_LD>
-__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int out_n0, int tid, const f16* cs, const uint4* pre) {
+__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int out_n0, int tid, const f16* cs, const uint4* pre,
+                                             bool nt) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
     const bool both = (e.flags & VD_EPI_RESIDUAL) && (e.flags & VD_EPI_ROWVEC);
 #pragma unroll
@@ -204,9 +206,12 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                     if (both) b.u = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + (float)b.e[i]);
-                    // streaming output: non-temporal so 20..80 MB of results do not evict the weight / activation panels
-                    // that the other tiles of this XCD keep re-reading from its 4 MiB L2
-                    vd_store16_nt(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col, o.u);
+                    // nt: streaming output that does not evict the weight / activation panels the other tiles of this
+                    // XCD keep re-reading from its 4 MiB L2 -- but then the NEXT kernel finds its input in HBM, not in
+                    // L2 / Infinity Cache; the host decides per launch (GemmArgs.nt_store)
+                    f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+                    if (nt) vd_store16_nt(dst, o.u);
+                    else *reinterpret_cast<uint4*>(dst) = o.u;
                 } else {
                     float v[8];
 #pragma unroll
@@ -238,10 +243,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int NMF = MI * NI;     // MFMAs per k-step and wave
     constexpr int RPP = NT / SLOTS;  // rows staged per pass: SLOTS threads per row
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
-    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    // a staging pass covers RPP rows; tiles that are not a multiple of it (128x320 / 128x160 with 32-deep K tiles) carry
+    // padding rows in LDS, which the last pass fills with zeros (out-of-range source offset)
+    constexpr int A_PASSES = (BM + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;
+    constexpr int BMP = A_PASSES * RPP, BNP = B_PASSES * RPP;
     constexpr int LPT = A_PASSES + B_PASSES;  // DMA pieces per thread and tile
-    constexpr int STAGE_BYTES = (BM + BN) * KROW_BYTES;
+    constexpr int STAGE_BYTES = (BMP + BNP) * KROW_BYTES;
     constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
     constexpr int EPI_BYTES = BM * CS_LD * 2;
     constexpr int D = STAGES - 1;  // prefetch distance in tiles
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     const int Hv = d.Hin << d.ups, Wv = d.Win << d.ups;
 #pragma unroll
     for (int ps = 0; ps < A_PASSES; ++ps) {
-        const int m = m0 + lrow + RPP * ps;
+        const int m = (BMP == BM || lrow + RPP * ps < BM) ? m0 + lrow + RPP * ps : d.M;  // padding rows: out of range
         if (m < d.M && p.plain) {  // plain matrix / 1x1 stride-1 conv: output row == input pixel, no index division
             a_iy0[ps] = 0;
             a_ix0[ps] = 0;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     unsigned dvoff_b[B_PASSES];
 #pragma unroll
     for (int ps = 0; ps < B_PASSES; ++ps) {
-        const int n = n0 + lrow + RPP * ps;
+        const int n = (BNP == BN || lrow + RPP * ps < BN) ? n0 + lrow + RPP * ps : d.N;
         dvoff_b[ps] = (n < d.N) ? (unsigned)((n * d.ldw + sw_slot * 8) * 2) : OOB_OFFSET;
     }
     unsigned dvoff_a[A_PASSES];
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         is_soff_a = (unsigned)((second ? n_cc - d.c0 : n_cc) * 2);
         is_soff_b = (unsigned)(kglob * 2);
         is_dst_a = lds0 + (unsigned)(buf * STAGE_BYTES) + wave_dst;
-        is_dst_b = is_dst_a + BM * KROW_BYTES;
+        is_dst_b = is_dst_a + BMP * KROW_BYTES;
         is_kmask = (ragged && (kglob + sw_slot * 8 >= d.K)) ? OOB_OFFSET : 0u;
         n_cc += KB;  // advance to the next K tile
         if (n_cc >= ctot) {
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         rd_a[ks] = lds_off_kb<KB>(wm * WM + l31, ks * 2 + hi);
-        rd_b[ks] = BM * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
+        rd_b[ks] = BMP * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
     }
     f16x8 fa[2][MI], fb[2][NI];  // double-buffered operand fragments; indices are compile-time after unrolling
     auto read_frags = [&](const char* st, int ks, f16x8* a, f16x8* b) {
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 s += __shfl_xor(s, o, 64);
                 q += __shfl_xor(q, o, 64);
             }
-            if (lslot == 0) {
+            if (lslot == 0 && lrow + RPP * ps < BM) {
                 const float inv_k = 1.0f / (float)d.K;
                 const float mean = s * inv_k;
                 float var = q * inv_k - mean * mean;
@@ -671,13 +678,14 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     __syncthreads();
 
     // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
-    if (geglu) epi_writeout<BM, BN / 16, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre);
-    else epi_writeout<BM, BN / 8, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre);
+    if (geglu) epi_writeout<BM, BN / 16, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre, p.nt_store != 0);
+    else epi_writeout<BM, BN / 8, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre, p.nt_store != 0);
 }
 
 template <int BM, int BN, int NT, int STAGES, int KB>
 constexpr int gemm_lds_bytes() {
-    constexpr int stage = (BM + BN) * KB * 2 * STAGES;
+    constexpr int rpp = NT / (KB / 8);
+    constexpr int stage = ((BM + rpp - 1) / rpp + (BN + rpp - 1) / rpp) * rpp * KB * 2 * STAGES;
     constexpr int epi = BM * (BN + 8) * 2 + BM * 8;  // epilogue tile + LayerNorm-fold row statistics
     return stage > epi ? stage : epi;
 }

@@ -165,6 +165,11 @@ class DDIMSampler(object):
             index = total_steps - i - 1
             ts.copy_(steps_dev[i].expand(nb))       # device-side refresh, no host sync
             coef.copy_(table[index])
+            # RNG contract: the reference draws noise_like(x) = torch.randn_like(x) on every step even when sigma = 0
+            # (ddim.py:167 / :294 there), so the device generator ends a sample() call advanced by one latent-sized draw
+            # per step.  Consumed here, outside the captured graph, so code that keeps drawing from the default generator
+            # after sample() sees the reference's stream.
+            torch.randn_like(xs)
             if i == 0 or not self.use_graph:
                 body()
             elif graph is None:
@@ -207,9 +212,13 @@ class DDIMSampler(object):
         else:
             eps = self.model.apply_model_multicontext(xi, t_in, c_info_list)
         sigma = float(self.ddim_sigmas[index])
-        noise = None
+        # drawn on every step like the reference's noise_like(x) (ddim.py:167 there): same generator consumption, and for
+        # eta > 0 the same noise values as a reference running in fp16 on this device
+        noise = torch.randn_like(x)
         if sigma != 0.:
-            noise = (torch.randn(x.shape, device=x.device, dtype=torch.float32) * temperature).to(torch.float16)
+            noise = noise if temperature == 1. else (noise.float() * temperature).to(torch.float16)
+        else:
+            noise = None
         return ops.cfg_ddim_step(x, eps.contiguous(), guided=guided, guidance_scale=float(scale),
                                  a_t=float(self.ddim_alphas[index]), a_prev=float(self.ddim_alphas_prev[index]),
                                  sigma=sigma, sqrt_one_minus_at=float(self.ddim_sqrt_one_minus_alphas[index]),

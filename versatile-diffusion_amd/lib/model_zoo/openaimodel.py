@@ -275,7 +275,8 @@ class UNetModel2D_Next(nn.Module, PackCache):
         Bn, E = emb_silu.shape
         for c, lst in groups.items():
             nb = len(lst)
-            o = ops.gemm(emb_silu, stacked[c], M=Bn, N=c, K=E, batch=nb, strides=(0, c * E, Bn * c, 0))
+            o = ops.gemm(emb_silu, stacked[c], M=Bn, N=c, K=E, batch=nb, strides=(0, c * E, Bn * c, 0),
+                         out_shape=(nb, Bn, c))
             for j, (i, _) in enumerate(lst):
                 out[i] = o[j]
         return out

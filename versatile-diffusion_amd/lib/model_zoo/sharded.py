@@ -40,19 +40,18 @@ def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = shape[0]
+    if B < world:  # deterministic from the arguments: every rank raises, nobody is left waiting in the all_gather
+        raise ValueError("sample_sharded: batch %d < world size %d (every rank needs at least one sample)" % (B, world))
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(device)  # kernels and the RCCL communicator of this rank live on its own GPU
     lo, hi = shard_bounds(B, world, rank)
     x_T = draw_initial_latent(shape, seed)[lo:hi].to(device)
     local_ctx = [_slice_ctx(ci, lo, hi) for ci in c_info_list]
-    if hi > lo:
-        images = decode_fn(sample_fn(x_T, local_ctx))
-    else:
-        images = None
+    images = decode_fn(sample_fn(x_T, local_ctx))
     if world == 1 or not gather:
         return images
     # ragged slices: pad to the largest slice so a single fixed-size all_gather does it
     max_n = shard_bounds(B, world, 0)[1]
-    if images is None:
-        raise RuntimeError("rank %d got an empty slice: need batch >= world size" % rank)
     pad = images
     if images.shape[0] < max_n:
         pad = torch.cat([images, images.new_zeros((max_n - images.shape[0],) + tuple(images.shape[1:]))])

@@ -5,6 +5,7 @@ kernel is enqueued on torch's current stream, so `torch.cuda.graph` capture and 
 No arithmetic is done in torch here.
 """
 import ctypes
+import functools
 import math
 
 import torch
@@ -457,3 +458,31 @@ def probe_mfma_layout(device):
     c_col = torch.zeros((64, 16), dtype=torch.int32, device=device)
     _check(lib().vd_probe_mfma_layout(_ptr(a_k), _ptr(c_row), _ptr(c_col), _stream()))
     return a_k.cpu(), c_row.cpu(), c_col.cpu()
+
+
+# ---- device guard ---------------------------------------------------------------------------------------------------
+# Kernels go to torch's current stream OF THE DEVICE THE TENSORS LIVE ON: when that is not the calling thread's current
+# device (model on cuda:1 while cuda:0 is current, as the reference allows) the call runs under torch.cuda.device(...);
+# operands spread over several devices are rejected.  The common case costs one integer comparison.
+def _guarded(fn):
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for t in list(args) + list(kwargs.values()):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise VdHipError("%s: operands live on different devices (%s and %s)" % (fn.__name__, dev, t.device))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows",
+              "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
+              "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
+              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16"):
+    globals()[_name] = _guarded(globals()[_name])
