@@ -1,20 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: 512x512 images/sec at 50 DDIM steps (BASELINE.json metric), synthetic inputs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload t2i|i2v|dual|triple]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: a guided (CFG 7.5) 50-step DDIM loop over a batch of
-`--batch` (default 4) 64x64x4 latents with a [B,77,768] text context, followed by the KL-f8 decode to 512x512
--- BASELINE.json configs[1] ("text-to-image 512x512, 50 DDIM steps, bs=4 fp16, 1xMI355X").  Context encoding
-(CLIP) is outside the timed region.  Inputs (latents, contexts, weights) are resident in HBM when
-timing starts.  With N > 1 every rank samples its own batch (batch-axis sharding, weak scaling) and the decoded
-images are all-gathered over RCCL inside the timed region.
+One "step" = one pass of the hot path over one batch: a guided (CFG 7.5) 50-step DDIM loop over the batch's latents,
+followed by the KL-f8 decode.  The default workload is BASELINE.json configs[1] ("text-to-image 512x512, 50 DDIM steps,
+bs=4 fp16, 1xMI355X": 4 latents of 64x64x4, text context [B,77,768]); --workload selects configs[2..4]: image variation
+(bs 8, + VAE encode, image context L=257), dual-guided (text + image context mixing, 2 per GPU = bs 16 on 8 GPUs) and the
+triple-context 768x768 blender (text + two masked images, L=514, 4 per GPU = bs 32 on 8 GPUs).  Context encoding (CLIP)
+is outside the timed region.  Inputs (contexts, images, weights) are resident in HBM when timing
+starts.  Every configuration goes through lib.model_zoo.sharded.vd_sample_sharded: the full-batch latent is drawn once
+and sliced per rank, each rank samples its slice (per-GPU batch fixed: weak scaling), and the decoded images are
+all-gathered over RCCL inside the timed region.
 
 The JSON line also carries
-  roofline      -- for the kernel that dominates a UNet forward: algorithmic FLOPs of its launches / their measured
-                   duration (events on the launch stream), against the dense fp16 MFMA peak of MI355X
+  unet_forward_ms_per_ddim_step_bsB -- BASELINE metric (ii): one guided DDIM step replayed from the sampler's HIP graph
+  roofline      -- for the kernel that dominates a UNet forward of the workload: algorithmic FLOPs of its launches /
+                   their measured duration (events on the launch stream), against the dense fp16 MFMA peak of MI355X
   cpu_baseline  -- the CPU fp32 oracle (oracle/vd_oracle.py, kind "port") timed on this host on a bounded sample
 """
 import argparse
@@ -67,29 +71,79 @@ def build_model(device, seed=0):
     return net
 
 
-def one_batch(net, sampler, batch, ctx, uctx, steps, seed, device):
-    torch.manual_seed(seed + 100)  # reference convention: torch.manual_seed(seed + 100), app.py:309
-    c_info = {"type": "text", "conditioning": ctx, "unconditional_conditioning": uctx,
-              "unconditional_guidance_scale": 7.5}
-    z, _ = sampler.sample(steps=steps, shape=[batch, 4, 64, 64], x_info={"type": "image"}, c_info=c_info, eta=0.,
-                          verbose=False)
-    return net.vae_decode(z, which="image")
+# ---- workloads = BASELINE.json configs[1..4] ----------------------------------------------------
+# gf_fwd: algorithmic GFLOP of ONE UNet forward per sample (reference graph, torch flop counter)
+FIDELITY = 0.02   # image-variation fidelity of the i2v workload: int(50 * 0.98) = 49 of the 50 DDIM steps run
+WORKLOADS = {
+    "t2i": dict(cfg=1, side=64, batch=4, global_fixed=False, ctxs=[("text", 77, 1.0)], gf_fwd=803.3, vae_dec=2514.5, vae_enc=0.0,
+                desc="text-to-image 512x512 (64x64x4 latent), single text-context flow"),
+    "i2v": dict(cfg=2, side=64, batch=8, global_fixed=False, ctxs=[("image", 257, 1.0)], gf_fwd=818.5, vae_dec=2514.5, vae_enc=1116.7,
+                desc="image-variation 512x512: KL-f8 VAE encode of the input images -> q_sample -> DDIM with the CLIP "
+                     "image context (L=257, zero unconditional context), fidelity 0.02 = 49 of 50 steps"),
+    "dual": dict(cfg=3, side=64, batch=16, global_fixed=True, ctxs=[("text", 77, 0.5), ("image", 257, 0.5)], gf_fwd=1203.4,
+                 vae_dec=2514.5, vae_enc=0.0,
+                 desc="dual-guided text (L=77, ratio 0.5) + image (L=257, ratio 0.5) context mixing 512x512, global batch 16 "
+                      "sharded on the batch axis"),
+    "triple": dict(cfg=4, side=96, batch=32, global_fixed=True, ctxs=[("text", 77, 0.4), ("image", 514, 0.6)], gf_fwd=3417.1,
+                   vae_dec=5754.3, vae_enc=0.0,
+                   desc="triple-context image blender 768x768 (96x96x4 latent): text (L=77, ratio 0.4) + two masked images "
+                        "(L=514, ratio 0.6), global batch 32 sharded on the batch axis"),
+}
 
 
-def roofline_leg(net, batch, ctx, uctx, device):
-    """One instrumented UNet forward at the benchmark shape (CFG batch 2B): per-launch events + algorithmic FLOPs."""
-    from vd_hip import ops
-    x = torch.randn(2 * batch, 4, 64, 64, device=device, dtype=torch.float16)
+def make_contexts(wl, n, device, seed):
+    """Synthetic CLIP-like contexts [n, L, 768] per context type + the unconditional ones the app uses (encoded empty
+    prompt for text -- one row repeated, app.py:305; all-zeros for images, app.py:345,475,562)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for ctype, L, ratio in wl["ctxs"]:
+        c = (torch.randn((n, L, 768), generator=g, device=device) * 0.5).half()
+        if ctype == "text":
+            u = (torch.randn((1, L, 768), generator=g, device=device) * 0.5).half().repeat(n, 1, 1)
+        else:
+            u = torch.zeros_like(c)
+        out.append({"type": ctype, "conditioning": c, "unconditional_conditioning": u,
+                    "unconditional_guidance_scale": 7.5, "ratio": ratio})
+    return out
+
+
+def one_batch(net, sampler, wl, ctxs, n_global, steps, seed, images=None):
+    """One pass of the hot path over one batch: (VAE encode -> q_sample ->) guided DDIM loop -> KL-f8 decode ->
+    all_gather, through lib.model_zoo.sharded.vd_sample_sharded: the full-batch latent is drawn ONCE with the reference's
+    seed rule (torch.manual_seed(seed + 100), app.py:309) and sliced per rank, the decoded images are all-gathered."""
+    from lib.model_zoo import sharded
+    return sharded.vd_sample_sharded(net, sampler, steps, [n_global, 4, wl["side"], wl["side"]], ctxs, seed,
+                                     images=images, fidelity=FIDELITY if images is not None else 0.)
+
+
+def forward_inputs(wl, batch, device):
+    side = wl["side"]
+    x = torch.randn(2 * batch, 4, side, side, device=device, dtype=torch.float16)
     t = torch.full((2 * batch,), 501, device=device, dtype=torch.long)
-    c = torch.cat([uctx, ctx])
+    cs = [{"type": ct, "c": torch.randn(2 * batch, L, 768, device=device, dtype=torch.float16) * 0.5, "ratio": r}
+          for ct, L, r in wl["ctxs"]]
+    return x, t, cs
+
+
+def run_forward(net, x, t, cs):
+    if len(cs) == 1:
+        return net.apply_model({"type": "image", "x": x}, t, cs[0])
+    return net.apply_model_multicontext({"type": "image", "x": x}, t, cs)
+
+
+def roofline_leg(net, wl, batch, device):
+    """One instrumented UNet forward at the workload's shape (CFG batch 2B): per-launch events on the launch stream +
+    algorithmic FLOPs per launch -> the kernel with the largest share of the forward and its fraction of the MFMA peak."""
+    from vd_hip import ops
+    x, t, cs = forward_inputs(wl, batch, device)
     for _ in range(2):
-        net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+        run_forward(net, x, t, cs)
     torch.cuda.synchronize()
     agg = {}
     reps = 3
     for _ in range(reps):
         ops.profile_begin()
-        net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+        run_forward(net, x, t, cs)
         for name, fl, by, ms in ops.profile_end():
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
@@ -99,14 +153,15 @@ def roofline_leg(net, batch, ctx, uctx, device):
     d = table[dom]
     achieved = d["gflop"] / d["ms"]  # GFLOP/ms == TFLOP/s
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 corrections
-    # applied) over tools/unet_forward.py -- PMC collection cannot run inside this process; null when not collected
+    # applied) over tools/unet_forward.py -- PMC collection cannot run inside this process; null when not collected for
+    # this kernel at this round's build
     traffic, traffic_note = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pt = json.load(f)
-        ent = pt["kernels"].get(dom)  # tools/pmc_traffic.py keys GEMM instantiations like this table does
-        if ent:
-            traffic, traffic_note = ent["hbm_side_bytes_per_launch"], "profiles/r01_pmc_traffic.json: " + pt["note"]
+        ent = pt["kernels"].get(dom)
+        if ent and wl["cfg"] == 1:
+            traffic, traffic_note = ent["hbm_side_bytes_per_launch"], "profiles/r02_pmc_traffic.json: " + pt["note"]
     except Exception:
         pass
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP16_PEAK_TFLOPS,
@@ -114,22 +169,65 @@ def roofline_leg(net, batch, ctx, uctx, device):
             "traffic_note": traffic_note,
             "launches_per_forward": d["launches"], "avg_launch_us": round(d["avg_us"], 1),
             "algorithmic_gflop_per_launch": round(d["gflop"] / max(d["launches"], 1), 2),
-            "forward_ms_instrumented": round(sum(v["ms"] for v in table.values()), 3)}
+            "forward_ms_instrumented": round(sum(v["ms"] for v in table.values()), 3),
+            "forward_algorithmic_tflop": round(2 * batch * wl["gf_fwd"] / 1e3, 3)}
     return roof, table
+
+
+def graph_step_ms(net, sampler, wl, batch, steps, device, reps=20):
+    """Device time of ONE guided DDIM step (CFG-batched UNet forward + CFG combine + DDIM update) replayed from the HIP
+    graph the sampler uses -- BASELINE metric (ii), HIP events over `reps` warm replays."""
+    from vd_hip import ops
+    side = wl["side"]
+    xs = torch.randn(batch, 4, side, side, device=device, dtype=torch.float16)
+    x_next, p0 = torch.empty_like(xs), torch.empty_like(xs)
+    ts = torch.full((2 * batch,), 501, device=device, dtype=torch.long)
+    sampler.make_schedule(steps, verbose=False)
+    coef = sampler._coef_table(steps, 7.5, device)[steps // 2].clone()
+    cis = []
+    for ct, L, r in wl["ctxs"]:
+        cis.append({"type": ct, "c": torch.randn(2 * batch, L, 768, device=device, dtype=torch.float16) * 0.5, "ratio": r,
+                    "kv_cache": {}})
+
+    def body():
+        xi = {"type": "image", "x": xs, "repeat": 2}
+        eps = net.apply_model(xi, ts, cis[0]) if len(cis) == 1 else net.apply_model_multicontext(xi, ts, cis)
+        ops.cfg_ddim_step_dev(xs, eps.contiguous(), coef, guided=True, x_prev=x_next, pred_x0=p0)
+
+    with torch.no_grad():
+        for _ in range(2):
+            body()
+        graph = sampler._capture(body)
+        if graph is None:
+            return None
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def cpu_baseline_leg(net, device):
     """CPU fp32 oracle on a bounded sample: one CFG-batch-2 UNet forward (64x64 latent, L=77) and one 32x32-latent
-    VAE decode (scaled x4 to 64x64 by area); extrapolated to images/sec at 50 steps."""
+    VAE decode (scaled x4 to 64x64 by area); extrapolated to images/sec at 50 steps.  Threads are pinned (VD_CPU_THREADS,
+    default 32: on the 128-thread hosts of the GPU boxes torch's default oversubscribes the memory system and the same
+    forward takes 4-5x longer than on 8 threads) and the count actually used is reported as `cores`."""
     from oracle import vd_oracle as O
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-    cores = torch.get_num_threads()
+    cores = max(1, min(int(os.environ.get("VD_CPU_THREADS", "32")), os.cpu_count() or 1))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     x = torch.randn((2, 4, 64, 64), generator=g)
     c = torch.randn((2, 77, 768), generator=g) * 0.5
     t = torch.tensor([501, 501])
     plan = O.unet_plan()
     with torch.no_grad():
+        O.apply_model(sd, plan, x[:, :, :16, :16].contiguous(), t, c, c_type="text", global_ptr="image")  # warm the allocator
         t0 = time.time()
         O.apply_model(sd, plan, x, t, c, c_type="text", global_ptr="image")
         t_fwd = time.time() - t0
@@ -137,10 +235,11 @@ def cpu_baseline_leg(net, device):
         t0 = time.time()
         O.vae_decode(sd, "vae.image", z)
         t_dec = (time.time() - t0) * 4.0
+    torch.set_num_threads(prev)
     per_image = 50 * t_fwd + t_dec
     return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle fp32: 1 UNet forward (CFG batch 2, 64x64x4 latent, L=77) = %.2f s; 1 VAE decode 32x32 "
-                      "latent x4 area = %.2f s; extrapolated 50*forward + decode per image" % (t_fwd, t_dec)}
+            "sample": "oracle fp32 on %d pinned threads: 1 UNet forward (CFG batch 2, 64x64x4 latent, L=77) = %.2f s; 1 VAE "
+                      "decode 32x32 latent x4 area = %.2f s; extrapolated 50*forward + decode per image" % (cores, t_fwd, t_dec)}
 
 
 def main():
@@ -148,12 +247,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed batches (each = 50 DDIM steps + decode)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t2i",
+                    help="t2i = BASELINE configs[1] (default, the config the metric is quoted on); i2v / dual / triple = configs[2..4]")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernel-table", default=None, help="write the per-kernel table of the roofline leg here")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -169,76 +271,79 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus or not distributed, "launch with --nproc-per-node == --gpus"
 
+    # batch: t2i / i2v keep the per-GPU batch fixed (weak scaling: N GPUs sample N x batch images per step);
+    # dual / triple have BASELINE's GLOBAL batch (16 / 32) sharded over the ranks (strong scaling); on fewer than 8 GPUs
+    # they run the per-GPU share of the 8-GPU configuration (2 / 4 per GPU) unless --batch says otherwise
+    if args.batch is not None:
+        per_gpu = args.batch
+    elif wl["global_fixed"]:
+        per_gpu = max(1, wl["batch"] // 8)
+    else:
+        per_gpu = wl["batch"]
+    n_global = per_gpu * world
+    scaling = "weak"
+
     from lib.model_zoo.ddim import DDIMSampler
     net = build_model(device)
     sampler = DDIMSampler(net)
-    B = args.batch
-    g = torch.Generator(device=device).manual_seed(1000 + rank)
-    ctx = (torch.randn((B, 77, 768), generator=g, device=device) * 0.5).half()
-    uctx = (torch.randn((1, 77, 768), generator=g, device=device) * 0.5).half().repeat(B, 1, 1)
+    ctxs = make_contexts(wl, n_global, device, 1000)   # same seed on every rank: the full batch, sliced per rank
+    images = None
+    if wl["vae_enc"]:
+        lo = per_gpu * rank
+        gi = torch.Generator(device=device).manual_seed(2000)
+        images = torch.rand((n_global, 3, 8 * wl["side"], 8 * wl["side"]), generator=gi, device=device).half()[lo:lo + per_gpu]
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
+    img = None
     for i in range(args.warmup):
-        img = one_batch(net, sampler, B, ctx, uctx, args.ddim_steps, i, device)
-        if distributed:
-            gathered = [torch.empty_like(img) for _ in range(world)]
-            dist.all_gather(gathered, img)
+        img = one_batch(net, sampler, wl, ctxs, n_global, args.ddim_steps, i, images)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        img = one_batch(net, sampler, B, ctx, uctx, args.ddim_steps, 10 + i, device)
-        if distributed:
-            if gathered is None:
-                gathered = [torch.empty_like(img) for _ in range(world)]
-            dist.all_gather(gathered, img)   # the one collective of the path: decoded images over RCCL/xGMI
+        img = one_batch(net, sampler, wl, ctxs, n_global, args.ddim_steps, 10 + i, images)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert img.shape == (B, 3, 512, 512) and bool(torch.isfinite(img).all())
+    px = 8 * wl["side"]
+    assert img.shape == (n_global, 3, px, px) and bool(torch.isfinite(img).all())
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
+    value = n_global * args.steps / elapsed
+    n_unet_steps = int(args.ddim_steps * (1 - FIDELITY)) if wl["vae_enc"] else args.ddim_steps
     out = {
-        "metric": "512x512 images/sec (50-step DDIM)", "value": round(value, 4), "unit": "images/s",
+        "metric": "%dx%d images/sec (50-step DDIM)" % (px, px), "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "text-to-image 512x512 (64x64x4 latent), %d DDIM steps, CFG 7.5, bs=%d per GPU, fp16, "
-                               "single text-context flow (vd_four_flow_v1-0 UNet 859.5M + text context blocks) + kl-f8 "
-                               "decode; CLIP context encoding outside the timed region" % (args.ddim_steps, B),
-                   "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": "batch-shard x%d" % world,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: %s; %d DDIM steps, CFG 7.5, bs=%d per GPU, fp16 (vd_four_flow_v1-0 UNet "
+                               "859.5M + context blocks of the 0-D net) + kl-f8 decode; CLIP context encoding outside the "
+                               "timed region" % (wl["cfg"], wl["desc"], args.ddim_steps, per_gpu),
+                   "name": args.workload, "global_batch": n_global, "ddim_steps": args.ddim_steps,
+                   "parallelism": "batch-shard x%d (latent drawn once and sliced, one all_gather of decoded images)" % world,
                    "weights": "random-init (fan-in scaled normal), no checkpoints offline",
                    "exact_reuse": "context K/V projections computed once per sample() (inside the timed region); data blocks "
                                   "in front of the first context block shared by the two CFG replicas; throughput is counted "
                                   "on the reference's algorithmic FLOPs"},
     }
     if rank == 0:
-        alg_tf = B * (2 * args.ddim_steps * UNET_GF_PER_SAMPLE + VAE_DECODE_GF) / 1e3
+        alg_tf = per_gpu * (2 * n_unet_steps * wl["gf_fwd"] + wl["vae_dec"] + wl["vae_enc"]) / 1e3
         out["algorithmic_tflop_per_step"] = round(alg_tf, 1)
         out["whole_path_tflops_per_gpu"] = round(alg_tf / (ms_per_step / 1e3), 1)
         out["whole_path_frac_of_mfma_peak"] = round(alg_tf / (ms_per_step / 1e3) / MFMA_FP16_PEAK_TFLOPS, 4)
         if not args.no_roofline:
-            # per-DDIM-step device time of the UNet forward + update, HIP events over 20 warm steps (metric ii)
-            x = torch.randn(B, 4, 64, 64, device=device, dtype=torch.float16)
-            sampler.make_schedule(args.ddim_steps, verbose=False)
-            c_info = {"type": "text", "c": torch.cat([uctx, ctx]), "kv_cache": {}}
-            for _ in range(3):
-                sampler._step(x, {"type": "image"}, [c_info], 501, 25, True, 7.5, 1.0, True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                sampler._step(x, {"type": "image"}, [c_info], 501, 25, True, 7.5, 1.0, True)
-            e1.record()
-            torch.cuda.synchronize()
-            out["unet_forward_ms_per_ddim_step_bs%d" % B] = round(e0.elapsed_time(e1) / 20, 3)
-            roof, table = roofline_leg(net, B, ctx, uctx, device)
+            # BASELINE metric (ii): device time of one guided DDIM step (UNet forward at CFG batch 2B + update) replayed
+            # from the sampler's HIP graph; 40 % of the MFMA peak <=> 2 * B * gf_fwd / 1 PFLOP/s
+            ms = graph_step_ms(net, sampler, wl, per_gpu, args.ddim_steps, device)
+            if ms is not None:
+                out["unet_forward_ms_per_ddim_step_bs%d" % per_gpu] = round(ms, 3)
+                out["unet_forward_frac_of_mfma_peak"] = round(2 * per_gpu * wl["gf_fwd"] / ms / 1e3 / MFMA_FP16_PEAK_TFLOPS, 4)
+            roof, table = roofline_leg(net, wl, per_gpu, device)
             out["roofline"] = roof
             if args.dump_kernel_table:
                 with open(args.dump_kernel_table, "w") as f:

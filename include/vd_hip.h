@@ -202,6 +202,19 @@ int vd_clip_preprocess_f16(const void* img, int img_kind, int B, int H, int W, i
  * torchvision ToPILImage on the output of vae_decode (reference app.py:319): mul(255) in the tensor's dtype, .byte(). */
 int vd_image_to_u8(const void* img, int img_kind, int B, int H, int W, uint8_t* out, hipStream_t stream);
 
+/* Mask -> per-token weights of the masked CLIP image context (lib/model_zoo/clip.py:104-122): masks [B,1,H,W]
+ * (mask_kind 0 = float32, 1 = float16) are clamped to [0,1], resized to size x size like F.interpolate(mode='bilinear')
+ * and averaged per patch x patch cell; out [B][1 + (size/patch)^2] fp32 = [global mean | patch means]. */
+int vd_mask_patch_weights(const void* masks, int mask_kind, int B, int H, int W, int size, int patch, float* out,
+                          hipStream_t stream);
+
+/* 'Simple' colour adjustment of image variation (app.py:373-379): per image and channel
+ *   out = clamp((img - mean(img)) / std(img) * std(ref) + mean(ref), 0, 1)   (unbiased std over the H*W pixels)
+ * img / out [B,3,H,W] fp16, ref [3,H,W] (ref_batch_stride = 0: one input image for the whole batch, as the app does) or
+ * [B,3,H,W] (ref_batch_stride = 3*H*W). */
+int vd_color_adjust_f16(const void* img, const void* ref, void* out, int B, int H, int W, int64_t ref_batch_stride,
+                        hipStream_t stream);
+
 /* diagnostics */
 const char* vd_last_error(void);
 int vd_abi_version(void);

@@ -525,3 +525,42 @@ def test_error_reporting(ops, dev):
         ops.gemm(a, w)
     with pytest.raises(VdHipError, match="GPU"):
         ops.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(64).half(), torch.zeros(64).half())
+
+
+@pytest.mark.parametrize("B,H,W,dtype", [(2, 512, 512, torch.float16), (1, 768, 512, torch.float32), (1, 224, 224, torch.float32),
+                                         (3, 100, 60, torch.float16)])
+def test_mask_patch_weights(ops, dev, B, H, W, dtype):
+    """vd_mask_patch_weights vs the reference's arithmetic (clip.py:104-122): clamp, F.interpolate(bilinear) to 224^2,
+    conv2d with a ones kernel / 196, global mean in front."""
+    g = torch.Generator().manual_seed(80 + H)
+    m = (torch.rand((B, 1, H, W), generator=g) * 1.4 - 0.2).to(dtype)     # values outside [0,1] exercise the clamp
+    m[0, :, : H // 3] = 1.0
+    mm = torch.clamp(m.float(), 0, 1)
+    mm = F.interpolate(mm, [224, 224], mode="bilinear")
+    gs = mm.mean(dim=[1, 2, 3]).view(B, 1)
+    vt = F.conv2d(mm, torch.ones(1, 1, 14, 14), stride=14).flatten(1) / 196.0
+    ref = torch.cat([gs, vt], 1)
+    out = ops.mask_patch_weights(m.to(dev))
+    assert out.shape == (B, 257) and out.dtype == torch.float32
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    ones = ops.mask_patch_weights(torch.ones((1, 1, 64, 64), device=dev))
+    assert (ones - 1.0).abs().max().item() < 1e-6
+
+
+def test_color_adjust(ops, dev):
+    """'Simple' colour adjustment (app.py:373-379) vs the same formula in fp32."""
+    g = torch.Generator().manual_seed(90)
+    im = (torch.rand((3, 3, 128, 96), generator=g) * torch.tensor([0.5, 0.9, 0.3]).view(1, 3, 1, 1) + 0.05).half()
+    cx = (torch.rand((1, 3, 128, 96), generator=g) * 0.6 + 0.3).half()
+    def ref_of(x, c):
+        xm, xs = x.float().view(3, -1).mean(-1)[:, None, None], x.float().view(3, -1).std(-1)[:, None, None]
+        cm, cs = c.float().view(3, -1).mean(-1)[:, None, None], c.float().view(3, -1).std(-1)[:, None, None]
+        return torch.clamp((x.float() - xm) / xs * cs + cm, 0, 1)
+    ref = torch.stack([ref_of(i, cx[0]) for i in im])
+    out = ops.color_adjust(im.to(dev), cx.to(dev))
+    assert (out.float().cpu() - ref).abs().max().item() < 2e-3
+    from lib.app_ops import color_adjust_simple
+    lst = color_adjust_simple([i.to(dev) for i in im], cx.to(dev))
+    assert isinstance(lst, list) and torch.equal(torch.stack(lst), out)
+    per = ops.color_adjust(im.to(dev), im.flip(0).contiguous().to(dev))     # one reference image per output image
+    assert (per.float().cpu() - torch.stack([ref_of(a, b) for a, b in zip(im, im.flip(0))])).abs().max().item() < 2e-3

@@ -4,8 +4,8 @@ HBM-side traffic table bench.py reads (profiles/rNN_pmc_traffic.json).
 usage: python tools/pmc_traffic.py <fetch_results.db> <write_results.db> > profiles/r01_pmc_traffic.json
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): gfx950 rocprofv3 reports half of the bytes of
-a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  GEMM instantiations are keyed without their
-(stages, K-depth) template arguments, matching the kernel names of bench.py's per-kernel table."""
+a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB.  GEMM instantiations are keyed
+like the kernel names of bench.py's per-kernel table (vd_gemm_config_name)."""
 import collections, json, re, sqlite3, sys
 
 
@@ -14,7 +14,7 @@ def norm(name):
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
         if m.group(1) == "gemm_f16_kernel":
-            args = args[:5]
+            args = args[:7]   # BM, BN, WM, WN, threads, stages, K depth (the 8th, the occupancy hint, is not part of bench.py's names)
         return "%s<%s>" % (m.group(1), ",".join(args))
     m = re.search(r"(gn_partial_kernel|gn_apply_kernel|gn_slab_kernel|layernorm_kernel|splitk_reduce_kernel)", name)
     return m.group(1) if m else None

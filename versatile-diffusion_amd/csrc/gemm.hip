@@ -226,13 +226,16 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         // weights of every layer come from HBM (1.7 GB per forward against 256 MB of Infinity Cache) and one 64-deep tile
         // of lead does not cover that latency (measured in-forward: 128x128 convs of the 32x32 level -14 %, 128x320
         // -4..9 %, GEGLU -3..5 %; split-K shapes and the small tiles lose 3-10 % and keep 64-deep tiles).
-        // VD_GEMM_VARIANT=0 switches it off, =q forces it, =h additionally runs the N = 320 layers on two 128x160 blocks
-        // per CU (development A/B runs).
+        // VD_GEMM_VARIANT=0 switches it off, =q forces it, =h also moves the short-K N = 320 layers to 128x160 blocks
+        // (development A/B runs).
         static const char* var_env = getenv("VD_GEMM_VARIANT");
         const char v = var_env ? var_env[0] : 'a';
         const int ktps = (a.kt_total + nsplit - 1) / nsplit;
         const bool deep_k = ktps >= 20 && nsplit == 1;
-        if (v == 'h' && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
+        // N = 320 / 640 / 960 layers of the 64x64 level: two independent 4-wave blocks of 128x160 per CU beat one 8-wave
+        // block of 128x320 by ~3 % over the forward although they fetch the activation panel twice -- the barrier
+        // groups are half as large and the two blocks drift out of phase (h = for every K, default = deep K only)
+        if ((v == 'h' || (v != '0' && deep_k)) && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
         if (v == 'q' || (v != '0' && (cfg == T128x128w8 ? d.M >= 2048 : deep_k))) {
             switch (cfg) {
                 case T128x128: cfg = T128x128q; break;

@@ -85,6 +85,90 @@ __global__ __launch_bounds__(256) void image_to_u8_kernel(const void* img, uint8
     out[i] = (uint8_t)load_level<KIND>(img, (b * 3 + c) * (size_t)HW + p);
 }
 
+// ---- mask -> per-token weights of the masked CLIP image encoder (reference lib/model_zoo/clip.py:104-122) -------------------
+// masks [B,1,H,W] -> clamp to [0,1] -> F.interpolate(bilinear, align_corners=False) to size x size -> per-patch mean
+// (the reference's conv2d with a ones kernel / patch^2) and the global mean in front: out [B][1 + (size/patch)^2] fp32.
+// One block per sample, one thread per patch (256 patches of 14x14 pixels for ViT-L/14 at 224): every interpolated
+// pixel is 4 reads of an L2-resident mask; the global mean is the mean of the (equal-sized) patch means.
+template <int KIND>
+__device__ __forceinline__ float load_mask(const void* m, size_t i) {
+    float v = KIND == 0 ? reinterpret_cast<const float*>(m)[i] : (float)reinterpret_cast<const f16*>(m)[i];
+    return fminf(fmaxf(v, 0.f), 1.f);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void mask_patch_weights_kernel(const void* masks, float* out, int H, int W, int size, int patch) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, grid = size / patch, np = grid * grid;
+    const float sy = (float)H / (float)size, sx = (float)W / (float)size;
+    const size_t base = (size_t)b * H * W;
+    float gsum = 0.f;
+    for (int pidx = threadIdx.x; pidx < np; pidx += 256) {
+        const int py = pidx / grid, px = pidx - py * grid;
+        float acc = 0.f;
+        for (int dy = 0; dy < patch; ++dy) {
+            // torch's area_pixel_compute_source_index (align_corners = False): src = scale * (dst + 0.5) - 0.5, clamped at 0
+            float fy = sy * ((float)(py * patch + dy) + 0.5f) - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+            const float ly = fy - (float)y0;
+            for (int dx = 0; dx < patch; ++dx) {
+                float fx = sx * ((float)(px * patch + dx) + 0.5f) - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+                const float lx = fx - (float)x0;
+                const float v00 = load_mask<KIND>(masks, base + (size_t)y0 * W + x0), v01 = load_mask<KIND>(masks, base + (size_t)y0 * W + x1);
+                const float v10 = load_mask<KIND>(masks, base + (size_t)y1 * W + x0), v11 = load_mask<KIND>(masks, base + (size_t)y1 * W + x1);
+                acc += (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            }
+        }
+        const float mean = acc / (float)(patch * patch);
+        out[(size_t)b * (np + 1) + 1 + pidx] = mean;
+        gsum += mean;
+    }
+    red[threadIdx.x] = gsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)b * (np + 1)] = red[0] / (float)np;
+}
+
+// ---- 'Simple' colour adjustment of image variation (reference app.py:373-379) ------------------------------------------------
+// out[b][c] = clamp((img[b][c] - mean(img[b][c])) / std(img[b][c]) * std(ref[c]) + mean(ref[c]), 0, 1), std unbiased over
+// the H*W pixels of a channel.  One block per (channel, image): statistics of both planes in fp32 (two sums each), then
+// the affine map; planes of 512^2 halfs are L2-resident for the second read.
+__global__ __launch_bounds__(256) void color_adjust_kernel(const f16* img, const f16* ref, f16* out, int HW, long ref_stride) {
+    __shared__ float red[4][256];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const f16* ip = img + ((size_t)b * 3 + c) * HW;
+    const f16* rp = ref + (size_t)b * ref_stride + (size_t)c * HW;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};  // sum img, sumsq img (shifted), sum ref, sumsq ref (shifted)
+    const float ki = (float)ip[0], kr = (float)rp[0];  // shift by the first sample: keeps the one-pass variance well conditioned
+    for (int i = tid; i < HW; i += 256) {
+        const float a = (float)ip[i] - ki, r = (float)rp[i] - kr;
+        s[0] += a; s[1] += a * a; s[2] += r; s[3] += r * r;
+    }
+    for (int q = 0; q < 4; ++q) red[q][tid] = s[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+            for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + o];
+        __syncthreads();
+    }
+    const float n = (float)HW;
+    const float mi = red[0][0] / n, mr = red[2][0] / n;
+    const float vi = fmaxf((red[1][0] - n * mi * mi) / (n - 1.f), 0.f), vr = fmaxf((red[3][0] - n * mr * mr) / (n - 1.f), 0.f);
+    const float scale = sqrtf(vr) / sqrtf(vi), mean_i = mi + ki, mean_r = mr + kr;
+    f16* op = out + ((size_t)b * 3 + c) * HW;
+    for (int i = tid; i < HW; i += 256) {
+        const float v = ((float)ip[i] - mean_i) * scale + mean_r;
+        op[i] = (f16)fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int vd_image_to_u8(const void* img, int img_kind, int B, int H, int W, uint8_t* out, hipStream_t stream) {
@@ -119,4 +203,24 @@ extern "C" int vd_clip_preprocess_f16(const void* img, int img_kind, int B, int 
     hipLaunchKernelGGL(resample_v_norm_kernel, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, stream, tmp, (f16*)out, H, size,
                        crop_t, vb, vk, vks, norm_table, tv);
     return vd_check_launch("vd_clip_preprocess_f16");
+}
+
+extern "C" int vd_mask_patch_weights(const void* masks, int mask_kind, int B, int H, int W, int size, int patch, float* out,
+                                     hipStream_t stream) {
+    VD_REQUIRE(masks && out, "vd_mask_patch_weights: null pointer");
+    VD_REQUIRE(B > 0 && H > 0 && W > 0, "vd_mask_patch_weights: empty input");
+    VD_REQUIRE(mask_kind == 0 || mask_kind == 1, "vd_mask_patch_weights: mask_kind must be 0 (f32) or 1 (f16)");
+    VD_REQUIRE(size > 0 && patch > 0 && size % patch == 0, "vd_mask_patch_weights: size=%d must be a multiple of patch=%d", size, patch);
+    if (mask_kind == 0) hipLaunchKernelGGL(mask_patch_weights_kernel<0>, dim3(B), dim3(256), 0, stream, masks, out, H, W, size, patch);
+    else hipLaunchKernelGGL(mask_patch_weights_kernel<1>, dim3(B), dim3(256), 0, stream, masks, out, H, W, size, patch);
+    return vd_check_launch("vd_mask_patch_weights");
+}
+
+extern "C" int vd_color_adjust_f16(const void* img, const void* ref, void* out, int B, int H, int W, int64_t ref_batch_stride,
+                                   hipStream_t stream) {
+    VD_REQUIRE(img && ref && out, "vd_color_adjust_f16: null pointer");
+    VD_REQUIRE(B > 0 && H > 0 && W > 0 && (size_t)H * W > 1, "vd_color_adjust_f16: empty input");
+    hipLaunchKernelGGL(color_adjust_kernel, dim3(3, B), dim3(256), 0, stream, (const f16*)img, (const f16*)ref, (f16*)out, H * W,
+                       (long)ref_batch_stride);
+    return vd_check_launch("vd_color_adjust_f16");
 }

@@ -13,7 +13,6 @@ tokens, divide by the norm of the projected pooled/CLS token, optional mask weig
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from vd_hip import ops, pack
 
@@ -246,18 +245,17 @@ class CLIPImageContextEncoder(AbstractEncoder):
         return ops.clip_preprocess(x, size)
 
     def vtoken_mask(self, masks):
-        """[B,1,H,W] mask -> per-token weights [B, 257] = [global mean | 14x14 patch means] of the mask resized to
-        224^2 bilinear (reference clip.py:104-122).  Returns None when the mask is all ones."""
+        """[B,1,H,W] mask -> per-token weights [B, 257] fp32 = [global mean | 14x14 patch means] of the mask clamped to
+        [0,1] and resized to 224^2 bilinear (reference clip.py:104-122), computed on the device (vd_mask_patch_weights).
+        The reference falls back to the unmasked encoder when the resized mask is all ones (a host sync on the mask
+        sum, clip.py:109-110); here an all-ones mask simply yields weights of 1, which scale nothing."""
         assert isinstance(masks, torch.Tensor) and masks.dim() == 4 and masks.shape[1] == 1
         size = self.model.config["vision"]["image_size"]
         p = self.model.config["vision"]["patch_size"]
-        m = torch.clamp(masks.float(), 0, 1)
-        m = F.interpolate(m, [size, size], mode="bilinear")
-        if m.sum() == m.numel():
-            return None
-        g = m.mean(dim=[1, 2, 3]).view(-1, 1)
-        pt = F.avg_pool2d(m, kernel_size=p, stride=p).flatten(1)
-        return torch.cat([g, pt], dim=1).to(self.get_device()).contiguous()
+        m = masks.to(device=self.get_device())
+        if m.dtype not in (torch.float32, torch.float16):
+            m = m.float()
+        return ops.mask_patch_weights(m, size, p)
 
     @torch.no_grad()
     def encode_pixels(self, pixel_values, token_scale=None):

@@ -160,16 +160,19 @@ class DDIMSampler(object):
             ops.cfg_ddim_step_dev(xs, eps.contiguous(), coef, guided=guided, x_prev=x_next, pred_x0=p0)
             xs.copy_(x_next)
 
+        # RNG contract: the reference draws noise_like(x) = torch.randn_like(x) on every step even when sigma = 0
+        # (ddim.py:167 / :294 there), so the device generator ends a sample() call advanced by one latent-sized draw per
+        # step.  The draws are consumed here, up front, and the generator state is pinned to that point after the loop
+        # (graph capture / replay bookkeeping must not leak into it), so code that keeps drawing from the default
+        # generator after sample() sees the reference's stream.
+        for _ in range(total_steps):
+            torch.randn_like(xs)
+        rng_after = torch.cuda.get_rng_state(dev)
         graph = None
         for i in range(total_steps):
             index = total_steps - i - 1
             ts.copy_(steps_dev[i].expand(nb))       # device-side refresh, no host sync
             coef.copy_(table[index])
-            # RNG contract: the reference draws noise_like(x) = torch.randn_like(x) on every step even when sigma = 0
-            # (ddim.py:167 / :294 there), so the device generator ends a sample() call advanced by one latent-sized draw
-            # per step.  Consumed here, outside the captured graph, so code that keeps drawing from the default generator
-            # after sample() sees the reference's stream.
-            torch.randn_like(xs)
             if i == 0 or not self.use_graph:
                 body()
             elif graph is None:
@@ -183,6 +186,7 @@ class DDIMSampler(object):
             if index % log_every_t == 0 or index == total_steps - 1:
                 intermediates["pred_xt"].append(xs.to(dtype).clone())
                 intermediates["pred_x0"].append(p0.to(dtype).clone())
+        torch.cuda.set_rng_state(rng_after, dev)
         return xs, p0
 
     def _capture(self, body):

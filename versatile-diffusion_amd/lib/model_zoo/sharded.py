@@ -64,13 +64,22 @@ def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group
     return torch.cat(parts)
 
 
-def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_scale=7.5, eta=0., group=None):
-    """t2i / multi-context sampling + kl-f8 decode of a full batch, sharded over the process group."""
+def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_scale=7.5, eta=0., group=None,
+                      images=None, fidelity=0.):
+    """t2i / image-variation / multi-context sampling + kl-f8 decode of a full batch, sharded over the process group.
+
+    images + fidelity > 0: image variation with fidelity (reference app.py:355-371) -- `images` is THIS RANK's slice of
+    the input images [n_local, 3, H, W] in [0, 1]; x0 = vae_encode(images) and only the first int(steps * (1 - fidelity))
+    DDIM steps run (ddim.py:97-103)."""
     def sample_fn(x_T, ctxs):
-        x_info = {"type": "image", "xt": x_T}
         for ci in ctxs:
             ci["unconditional_guidance_scale"] = guidance_scale
         lshape = [x_T.shape[0]] + list(shape[1:])
+        if images is not None and fidelity > 0.:
+            x_info = {"type": "image", "x0": net.vae_encode(images, which="image"),
+                      "x0_forward_timesteps": int(steps * (1 - fidelity))}
+        else:
+            x_info = {"type": "image", "xt": x_T}
         if len(ctxs) == 1:
             z, _ = sampler.sample(steps=steps, shape=lshape, x_info=x_info, c_info=ctxs[0], eta=eta, verbose=False)
         else:

@@ -444,6 +444,29 @@ def clip_preprocess(images, size=224):
     return out
 
 
+def mask_patch_weights(masks, size=224, patch=14):
+    """[B,1,H,W] float32 / float16 mask -> fp32 [B, 1 + (size/patch)^2] = [global mean | patch means] of the mask clamped
+    to [0,1] and resized bilinearly to size x size (reference clip.py:104-122)."""
+    assert masks.dim() == 4 and masks.shape[1] == 1 and masks.is_cuda and masks.dtype in (torch.float32, torch.float16)
+    m = masks.contiguous()
+    B, _, H, W = m.shape
+    out = torch.empty((B, 1 + (size // patch) ** 2), dtype=torch.float32, device=m.device)
+    _check(lib().vd_mask_patch_weights(_ptr(m), 0 if m.dtype == torch.float32 else 1, B, H, W, size, patch, _ptr(out), _stream()))
+    return out
+
+
+def color_adjust(images, ref):
+    """'Simple' colour adjustment (reference app.py:373-379): images [B,3,H,W] fp16, ref [3,H,W] / [1,3,H,W] (one input
+    image for the whole batch) or [B,3,H,W] -> clamp((img - mean) / std * std(ref) + mean(ref), 0, 1) per channel."""
+    _req(images, "images"); _req(ref, "ref")
+    B, C, H, W = images.shape
+    assert C == 3 and ref.shape[-3:] == (3, H, W)
+    per_image = ref.dim() == 4 and ref.shape[0] == B and B > 1
+    out = torch.empty_like(images)
+    _check(lib().vd_color_adjust_f16(_ptr(images), _ptr(ref), _ptr(out), B, H, W, 3 * H * W if per_image else 0, _stream()))
+    return out
+
+
 def probe_lds_tr16(addr_bytes):
     """addr_bytes: (64,) int32 per-lane LDS byte addresses -> (64, 4) int16 values read by ds_read_b64_tr_b16."""
     _req(addr_bytes, "addr_bytes", torch.int32)
@@ -484,5 +507,5 @@ def _guarded(fn):
 for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
-              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16"):
+              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust"):
     globals()[_name] = _guarded(globals()[_name])
