@@ -215,6 +215,16 @@ int vd_mask_patch_weights(const void* masks, int mask_kind, int B, int H, int W,
 int vd_color_adjust_f16(const void* img, const void* ref, void* out, int B, int H, int W, int64_t ref_batch_stride,
                         hipStream_t stream);
 
+/* Focus control of the image context ("adjust_rank", app.py:48-127): per sample x [L][C] (fp16 in, fp16 out)
+ *   A = x - rowmean(x);  U = top-q left singular vectors of A (= what torch.pca_lowrank(q, niter=100) converges to)
+ *   x_new = keep * A + sum_i g[i] * U[:,i] (U[:,i]^T A) + rowmean(x);   y = x_new * std(x) / std(x_new)   (unbiased std)
+ * with g[i] = f_i - keep from the reference's level -> singular-value-scale curves (host side, lib/app_ops.py); keep = 1
+ * keeps the remainder beyond rank q (lvl < 0.5), keep = 0 drops it (lvl > 0.5).  U comes from `iters` steps of a
+ * 32-column subspace iteration on A A^T in fp32.  32 <= L <= 512, q <= 32.  ws: vd_adjust_rank_workspace_bytes(). */
+int vd_adjust_rank_f16(const void* x, void* y, int B, int L, int C, int q, const float* g, float keep, int iters, float* ws,
+                       hipStream_t stream);
+size_t vd_adjust_rank_workspace_bytes(int B, int L, int C, int q);
+
 /* diagnostics */
 const char* vd_last_error(void);
 int vd_abi_version(void);

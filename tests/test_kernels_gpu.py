@@ -564,3 +564,39 @@ def test_color_adjust(ops, dev):
     assert isinstance(lst, list) and torch.equal(torch.stack(lst), out)
     per = ops.color_adjust(im.to(dev), im.flip(0).contiguous().to(dev))     # one reference image per output image
     assert (per.float().cpu() - torch.stack([ref_of(a, b) for a, b in zip(im, im.flip(0))])).abs().max().item() < 2e-3
+
+
+def test_adjust_rank_vs_reference_fixture(ops, dev):
+    """vd_adjust_rank_f16 behind lib.app_ops.adjust_rank (focus control, app.py:48-127) against the fixture the
+    reference's own code produced, for semantic (lvl < 0.5) and style (lvl > 0.5) levels; tolerance = fp16 rounding of
+    input / output + convergence of the subspace iteration."""
+    import numpy as np
+    from vdtest_util import load_gold
+    from lib.app_ops import adjust_rank
+    g = load_gold("adjust_rank.npz")
+    x = torch.from_numpy(g["x"]).to(dev)
+    ar = adjust_rank(max_drop_rank=[1, 5], q=20)
+    for lvl, key in ((0.0, "y_00"), (0.3, "y_03"), (0.8, "y_08"), (1.0, "y_10")):
+        y = ar(x, lvl)
+        assert y.dtype == torch.float16 and y.shape == x.shape
+        assert rel_l2(y, torch.from_numpy(g[key])) < 2e-3, lvl
+    assert ar(x, 0.5) is x
+
+
+def test_adjust_rank_batched_and_257_tokens(ops, dev):
+    """Batch of 2 different samples and L = 257 (disentanglement_noglobal = False feeds all tokens) against the exact-SVD
+    form of the same reconstruction (oracle.adjust_rank.exact)."""
+    from oracle import adjust_rank as A
+    from lib.app_ops import adjust_rank
+    gen = torch.Generator().manual_seed(3)
+    xs = []
+    for b in range(2):
+        u, _ = torch.linalg.qr(torch.randn(257, 40, generator=gen, dtype=torch.float64))
+        v, _ = torch.linalg.qr(torch.randn(768, 40, generator=gen, dtype=torch.float64))
+        s = (5.0 + b) * 0.8 ** torch.arange(40, dtype=torch.float64)
+        xs.append((u * s) @ v.T + 0.003 * torch.randn(257, 768, generator=gen, dtype=torch.float64) + 0.1 * b)
+    x = torch.stack(xs).half()
+    ar = adjust_rank()
+    for lvl in (0.2, 0.9):
+        y = ar(x.to(dev), lvl)
+        assert rel_l2(y, A.exact(x.float(), lvl)) < 2e-3, lvl

@@ -170,3 +170,24 @@ def test_clip_tiny(meta):
         assert not all_ones
         zm = O.clip_image_context(sd, "ctx.text.model", px, vc["num_attention_heads"], vc["num_hidden_layers"], vtoken_mask=vt)
         assert rel(zm, g["z_img_masked"]) < 1e-5
+
+
+def test_adjust_rank_oracle_vs_reference_fixture():
+    """oracle/adjust_rank.py (restatement of app.py:48-127) against tests/golden/adjust_rank.npz, which the REFERENCE's own
+    source lines produced (oracle/gen_golden_adjust_rank.py).  pca_lowrank is randomised: another seed must land on the
+    same reconstruction; the exact-SVD limit the device kernel computes agrees to fp16 output rounding."""
+    from oracle import adjust_rank as A
+    g = load("adjust_rank.npz")
+    x = torch.from_numpy(g["x"])
+    for lvl, key in ((0.0, "y_00"), (0.3, "y_03"), (0.8, "y_08"), (1.0, "y_10")):
+        torch.manual_seed(99)
+        assert rel(A.adjust_rank(x.clone(), lvl), g[key]) < 1e-4, lvl
+        assert rel(A.exact(x.float(), lvl), g[key]) < 5e-4, lvl
+    assert A.adjust_rank(x, 0.5) is x
+    # the product's host-side level curves are the reference's
+    from lib.app_ops import adjust_rank
+    ar = adjust_rank(max_drop_rank=[1, 5], q=20)
+    for lvl in (0.0, 0.1, 0.3, 0.49, 0.51, 0.8, 1.0):
+        f, keep = ar.scales(lvl)
+        fo, ko = A.level_scales(lvl)
+        assert keep == ko and np.allclose(f, fo, rtol=0, atol=1e-12), lvl

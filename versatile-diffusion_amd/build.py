@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "norm.hip", "attention.hip", "elementwise.hip", "preprocess.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "norm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "vd_probe_mfma_layout": (_I, [_P, _P, _P, _P]),
     "vd_probe_lds_tr16": (_I, [_P, _P, _P]),
     "vd_image_to_u8": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "vd_adjust_rank_f16": (_I, [_P, _P, _I, _I, _I, _I, _P, _F, _I, _P, _P]),
+    "vd_adjust_rank_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vd_mask_patch_weights": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vd_color_adjust_f16": (_I, [_P, _P, _P, _I, _I, _I, _L, _P]),
     "vd_clip_preprocess_f16": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

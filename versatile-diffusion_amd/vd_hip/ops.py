@@ -467,6 +467,18 @@ def color_adjust(images, ref):
     return out
 
 
+def adjust_rank(x, g, keep, iters=64):
+    """x [B, L, C] fp16 -> keep * A + sum_i g[i] u_i u_i^T A + row means, rescaled to x's std (vd_adjust_rank_f16);
+    g: fp32 [q] device tensor of singular-value scale offsets, keep in {0., 1.}."""
+    _req(x, "x"); _req(g, "g", torch.float32)
+    B, L, C = x.shape
+    q = g.numel()
+    ws = workspace(lib().vd_adjust_rank_workspace_bytes(B, L, C, q), x.device, "adjust_rank")
+    y = torch.empty_like(x)
+    _check(lib().vd_adjust_rank_f16(_ptr(x), _ptr(y), B, L, C, q, _ptr(g), float(keep), int(iters), _ptr(ws), _stream()))
+    return y
+
+
 def probe_lds_tr16(addr_bytes):
     """addr_bytes: (64,) int32 per-lane LDS byte addresses -> (64, 4) int16 values read by ds_read_b64_tr_b16."""
     _req(addr_bytes, "addr_bytes", torch.int32)
@@ -507,5 +519,5 @@ def _guarded(fn):
 for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
-              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust"):
+              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
     globals()[_name] = _guarded(globals()[_name])
