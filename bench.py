@@ -214,11 +214,11 @@ def graph_step_ms(net, sampler, wl, batch, steps, device, reps=20):
 def cpu_baseline_leg(net, device):
     """CPU fp32 oracle on a bounded sample: one CFG-batch-2 UNet forward (64x64 latent, L=77) and one 32x32-latent
     VAE decode (scaled x4 to 64x64 by area); extrapolated to images/sec at 50 steps.  Threads are pinned (VD_CPU_THREADS,
-    default 32: on the 128-thread hosts of the GPU boxes torch's default oversubscribes the memory system and the same
-    forward takes 4-5x longer than on 8 threads) and the count actually used is reported as `cores`."""
+    default 16 = the fastest setting measured on the GPU boxes' 256-thread hosts: 8 / 16 / 32 / 64 / 128 threads take 5.1 /
+    4.2 / 4.6 / 6.3 / 11.2 s for this forward) and the count actually used is reported as `cores`."""
     from oracle import vd_oracle as O
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-    cores = max(1, min(int(os.environ.get("VD_CPU_THREADS", "32")), os.cpu_count() or 1))
+    cores = max(1, min(int(os.environ.get("VD_CPU_THREADS", "16")), os.cpu_count() or 1))
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
@@ -342,7 +342,7 @@ def main():
             ms = graph_step_ms(net, sampler, wl, per_gpu, args.ddim_steps, device)
             if ms is not None:
                 out["unet_forward_ms_per_ddim_step_bs%d" % per_gpu] = round(ms, 3)
-                out["unet_forward_frac_of_mfma_peak"] = round(2 * per_gpu * wl["gf_fwd"] / ms / 1e3 / MFMA_FP16_PEAK_TFLOPS, 4)
+                out["unet_forward_frac_of_mfma_peak"] = round(2 * per_gpu * wl["gf_fwd"] / ms / MFMA_FP16_PEAK_TFLOPS, 4)
             roof, table = roofline_leg(net, wl, per_gpu, device)
             out["roofline"] = roof
             if args.dump_kernel_table:

@@ -46,6 +46,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
 #define VD_ACT_QUICK_GELU 2 /* x * sigmoid(1.702 x)  (HF CLIP)                                 */
 #define VD_ACT_SILU 3
+#define VD_ACT_GELU_TANH 4  /* 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  (GPT-2 MLP of the Optimus decoder) */
 
 /*
  * One fused GEMM / implicit-GEMM convolution:
@@ -125,7 +126,8 @@ int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y
 
 /* Fused softmax(Q K^T * scale) V, online softmax, no score tensor in HBM.
  * q [B][Nq][ldq], k/v [B][Nk][ldk/ldv], out [B][Nq][ldo]; head h occupies columns h*D..h*D+D-1.
- * D in {40, 64, 80, 160}.  causal != 0 masks key > query (CLIP text tower).
+ * D in {40, 64, 80, 160}.  causal = 1 masks key > query (CLIP text tower); causal = 1 + n masks key > query + n (n memory
+ * slots in front of the keys that every query sees: the latent memory of the Optimus GPT-2 decoder, n = 1).
  * Replaces CrossAttention.forward einsum/softmax/einsum (lib/model_zoo/attention.py:176-191). */
 int vd_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                      int ldq, int ldk, int ldv, int ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so,
@@ -133,6 +135,9 @@ int vd_attention_f16(const void* q, const void* k, const void* v, void* out, int
 
 /* Row softmax fp32 [rows][n] -> fp16 (VAE AttnBlock, lib/model_zoo/autokl_modules.py:192). */
 int vd_softmax_rows_f32_f16(const float* s, void* p, int64_t rows, int n, hipStream_t stream);
+/* softmax(scale * s) per row in fp32: token probabilities of the Optimus GPT-2 decoder, scale = 1 / temperature
+ * (lib/model_zoo/optimus.py:679-681: logits / temperature -> softmax -> multinomial). */
+int vd_softmax_rows_f32_f32(const float* s, float* p, int64_t rows, int n, float scale, hipStream_t stream);
 
 /* Sinusoidal timestep embedding, fp32 math, fp16 out [B][dim] = [cos | sin].
  * Replaces timestep_embedding (lib/model_zoo/diffusion_utils.py:131-151). */

@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE (oracle): CPU fp32 restatement of the Optimus GPT-2 decoder forward and of the decode loop --
+/root/reference/lib/model_zoo/optimus_models/optimus_gpt2.py:99-246 (gelu, Attention, MLP, Block), :870-993
+(GPT2Model_XX.forward with the latent as embedding AND per-layer memory), :1084-1100 (tied lm_head), and
+/root/reference/lib/model_zoo/optimus.py:662-688 (sample_single_sequence_conditional).  Never imported by the product.
+
+Pinned by tests/golden/optimus_tiny.npz: oracle/gen_golden_optimus.py runs the REFERENCE's own vendored
+GPT2ForLatentConnector_XX (imported from /root/reference) on a down-sized config with seeded synthetic weights."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def gelu(x):
+    """optimus_gpt2.py:99-100"""
+    return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def _conv1d(sd, p, x):
+    """modeling_utils.py:420-424: x @ weight + bias, weight [in, out]"""
+    return x @ sd[p + ".weight"] + sd[p + ".bias"]
+
+
+def gpt2_logits(sd, p, input_ids, z, n_head, n_layer, eps=1e-5):
+    """GPT2ForLatentConnector_XX.forward(input_ids [B, T], past = z [B, latent]) -> logits [B, T, V].
+    sd keys under `p` (e.g. 'decoder'): transformer.{wte,wpe,h.i...,ln_f,linear,linear_emb}, lm_head tied to wte."""
+    t = p + ".transformer"
+    B, T = input_ids.shape
+    E = sd[t + ".wte.weight"].shape[1]
+    past_emb = z @ sd[t + ".linear_emb.weight"].t()                       # :876
+    mem = (z @ sd[t + ".linear.weight"].t()).view(B, n_layer, E)          # :879-889: one [B, 1, E] key = value per layer
+    pos = torch.arange(1, T + 1)                                          # :900 past_length = 1
+    h = sd[t + ".wte.weight"][input_ids] + sd[t + ".wpe.weight"][pos][None] + past_emb[:, None]   # :941-953
+    D = E // n_head
+    for i in range(n_layer):
+        b = "%s.h.%d" % (t, i)
+        x = F.layer_norm(h, (E,), sd[b + ".ln_1.weight"], sd[b + ".ln_1.bias"], eps)
+        q, k, v = _conv1d(sd, b + ".attn.c_attn", x).split(E, dim=2)       # :182-183
+        k = torch.cat([mem[:, i:i + 1], k], dim=1)                          # :189-196: memory slot in front
+        v = torch.cat([mem[:, i:i + 1], v], dim=1)
+        sh = lambda a: a.view(B, a.shape[1], n_head, D).permute(0, 2, 1, 3)
+        w = torch.matmul(sh(q), sh(k).transpose(-1, -2)) / math.sqrt(D)   # :145-147
+        nd, ns = w.shape[-2], w.shape[-1]
+        mask = torch.tril(torch.ones(ns, ns))[ns - nd:ns, :ns]            # :149
+        w = w * mask - 1e4 * (1 - mask)
+        a = torch.matmul(torch.softmax(w, dim=-1), sh(v)).permute(0, 2, 1, 3).reshape(B, T, E)
+        h = h + _conv1d(sd, b + ".attn.c_proj", a)                        # :241
+        x = F.layer_norm(h, (E,), sd[b + ".ln_2.weight"], sd[b + ".ln_2.bias"], eps)
+        h = h + _conv1d(sd, b + ".mlp.c_proj", gelu(_conv1d(sd, b + ".mlp.c_fc", x)))   # :242-243
+    h = F.layer_norm(h, (E,), sd[t + ".ln_f.weight"], sd[t + ".ln_f.bias"], eps)
+    return h @ sd[t + ".wte.weight"].t()                                    # lm_head tied to wte
+
+
+def sample_sequence(sd, p, z, bos, eos, n_head, n_layer, max_length=30, temperature=1.0, generator=None):
+    """optimus.py:662-688 with top_k = 0, top_p = 1.0 (the decode() defaults): full-prefix forward per token,
+    multinomial on softmax(logits / temperature)."""
+    generated = torch.tensor([[bos]], dtype=torch.long)
+    while True:
+        lg = gpt2_logits(sd, p, generated, z[None], n_head, n_layer)[0, -1] / temperature
+        nxt = torch.multinomial(F.softmax(lg, dim=-1), num_samples=1, generator=generator)
+        generated = torch.cat([generated, nxt[None]], dim=1)
+        if int(nxt) == eos:
+            break
+        if generated.shape[1] >= max_length:
+            generated[0, -1] = eos
+            break
+    return generated[0]

@@ -191,3 +191,52 @@ def test_adjust_rank_oracle_vs_reference_fixture():
         f, keep = ar.scales(lvl)
         fo, ko = A.level_scales(lvl)
         assert keep == ko and np.allclose(f, fo, rtol=0, atol=1e-12), lvl
+
+
+def _optimus_sd():
+    meta_o = json.load(open(os.path.join(GOLD, "optimus_tokenizer.json")))
+    cfg, seed = meta_o["config"], meta_o["seed"]
+    from lib.model_zoo.optimus import optimus_gpt2_connector
+    net = optimus_gpt2_connector(cfg, latent_size=cfg["latent_size"])
+    shapes = {"decoder." + k: v for k, v in synth.shapes_of(net).items()}
+    sd = synth.synth_state_dict(shapes, seed)
+    sd["decoder.lm_head.weight"] = sd["decoder.transformer.wte.weight"]     # tie_weights
+    return meta_o, cfg, net, sd
+
+
+def test_optimus_gpt2_oracle_vs_reference_fixture():
+    """oracle/optimus_oracle.py (GPT-2 decoder with the latent as embedding + per-layer memory, and the sampling loop)
+    against outputs of the REFERENCE's vendored GPT2ForLatentConnector_XX (oracle/gen_golden_optimus.py); the product
+    module's state-dict key layout equals the reference module's (same synthetic-weight names were used there)."""
+    from oracle import optimus_oracle as OO
+    meta_o, cfg, net, sd = _optimus_sd()
+    g = load("optimus_tiny.npz")
+    lg = OO.gpt2_logits(sd, "decoder", T(g["ids"]), T(g["z"]), cfg["n_head"], cfg["n_layer"])
+    assert rel(lg, g["logits"]) < 1e-5
+    torch.manual_seed(99)
+    seq = OO.sample_sequence(sd, "decoder", T(g["z"])[0], 5, 7, cfg["n_head"], cfg["n_layer"], max_length=12)
+    assert seq.tolist() == g["sampled"].tolist()
+    # reference state-dict names: every tensor the reference module holds exists here with the same shape
+    expect = {"transformer.wte.weight", "transformer.wpe.weight", "transformer.h.0.attn.bias", "transformer.h.1.mlp.c_proj.weight",
+              "transformer.linear.weight", "transformer.linear_emb.weight", "transformer.ln_f.bias", "lm_head.weight"}
+    assert expect <= set(net.state_dict())
+    assert net.state_dict()["transformer.h.0.attn.c_attn.weight"].shape == (cfg["n_embd"], 3 * cfg["n_embd"])
+    assert net.lm_head.weight is net.transformer.wte.weight
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/model_zoo/optimus_models/vocab/gpt2-vocab.json"),
+                    reason="GPT-2 vocabulary files live in the reference checkout")
+def test_gpt2_tokenizer_matches_reference():
+    """The product's GPT-2 byte-level BPE (lib/model_zoo/optimus.py) against ids / decoded strings the reference's
+    vendored tokenizer produced (tests/golden/optimus_tokenizer.json)."""
+    from lib.model_zoo.optimus import optimus_gpt2_tokenizer
+    tk = json.load(open(os.path.join(GOLD, "optimus_tokenizer.json")))["tokenizer"]
+    v = "/root/reference/lib/model_zoo/optimus_models/vocab/"
+    tok = optimus_gpt2_tokenizer(vocab_file=v + "gpt2-vocab.json", merges_file=v + "gpt2-merges.txt")
+    tok.add_special_tokens({"pad_token": "<PAD>", "bos_token": "<BOS>", "eos_token": "<EOS>"})
+    assert [tok.encode("<BOS>"), tok.encode("<EOS>"), tok.encode("<PAD>")] == tk["special"] and len(tok) == tk["len"]
+    for c in tk["cases"]:
+        ids = tok.encode("<BOS>") + tok.encode(c["text"]) + tok.encode("<EOS>")
+        assert ids == c["ids"], c["text"]
+        assert tok.decode(ids, clean_up_tokenization_spaces=True) == c["decoded"]
+    assert tok.encode("<BOS> hello <EOS>") == tok.encode("<BOS>") + tok.encode("hello") + tok.encode("<EOS>")

@@ -575,11 +575,14 @@ def test_sampler_rng_consumption_matches_reference(tiny, dev, eta):
     ct = {"type": "text", "conditioning": T(gold["c_text"], dev), "unconditional_conditioning": T(gold["u_text"], dev),
           "unconditional_guidance_scale": 7.5}
     torch.manual_seed(77)
-    DDIMSampler(tiny).sample(steps=steps, shape=shape, x_info={"type": "image"}, c_info=dict(ct), eta=eta, verbose=False)
+    sampler = DDIMSampler(tiny)
+    sampler.sample(steps=steps, shape=shape, x_info={"type": "image"}, c_info=dict(ct), eta=eta, verbose=False)
     after = torch.randn(8, device=dev)
+    n_steps = len(sampler.ddim_timesteps)      # 7 for steps = 6: arange(0, 1000, 1000 // 6) has 7 entries, all are run
+    assert n_steps == 7
     torch.manual_seed(77)
     x = torch.randn(shape, device=dev, dtype=torch.float16)     # ddim.py:105: randn(shape, device, dtype of the context)
-    for _ in range(steps):
+    for _ in range(n_steps):
         torch.randn_like(x)                                       # ddim.py:167
     expect = torch.randn(8, device=dev)
     assert torch.equal(after, expect)

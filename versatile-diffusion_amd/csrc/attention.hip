@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     int ntiles = (p.Nk + KV - 1) / KV;
     if (p.causal) {
         const int last_q = min(qb * QB + QB - 1, p.Nq - 1);
-        ntiles = min(ntiles, last_q / KV + 1);
+        ntiles = min(ntiles, (last_q + p.causal - 1) / KV + 1);  // causal = 1 + offset: key <= query + offset is visible
     }
 
     // per-lane LDS byte offsets of the operand reads inside a tile
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         // ---- online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
         const int key0 = t * KV;
         // masking is needed only on the ragged last tile / on tiles that cross the causal diagonal (wave-uniform)
-        const bool need_mask = (key0 + KV > p.Nk) || (p.causal && (key0 + KV - 1 > qb * QB + wave * 32));
+        const bool need_mask = (key0 + KV > p.Nk) || (p.causal && (key0 + KV - 1 > qb * QB + wave * 32 + p.causal - 1));
         if (need_mask) {
 #pragma unroll
             for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.Nk || (p.causal && key > qrow)) st[kt][r] = -INFINITY;
+                    if (key >= p.Nk || (p.causal && key > qrow + p.causal - 1)) st[kt][r] = -INFINITY;
                 }
         }
         float mx = st[0][0];
@@ -328,26 +328,27 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     }
 }
 
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, f16* pout, int n) {
+template <typename OUT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, OUT* pout, int n, float scale) {
     const size_t row = blockIdx.x;
     const float* sr = s + row * n;
-    f16* pr = pout + row * n;
+    OUT* pr = pout + row * n;
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float mx = -INFINITY;
-    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sr[i]);
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, sr[i] * scale);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
-    for (int i = tid; i < n; i += 256) sum += __expf(sr[i] - mx);
+    for (int i = tid; i < n; i += 256) sum += __expf(sr[i] * scale - mx);
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
     const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
-    for (int i = tid; i < n; i += 256) pr[i] = (f16)(__expf(sr[i] - mx) * inv);
+    for (int i = tid; i < n; i += 256) pr[i] = (OUT)(__expf(sr[i] * scale - mx) * inv);
 }
 
 template <int D>
@@ -389,6 +390,13 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
 extern "C" int vd_softmax_rows_f32_f16(const float* s, void* p, int64_t rows, int n, hipStream_t stream) {
     VD_REQUIRE(s && p && rows > 0 && n > 0, "vd_softmax_rows_f32_f16: bad arguments");
     VD_REQUIRE(rows < (1ll << 31), "vd_softmax_rows_f32_f16: too many rows");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, s, (f16*)p, n);
+    hipLaunchKernelGGL(softmax_rows_kernel<f16>, dim3((unsigned)rows), dim3(256), 0, stream, s, (f16*)p, n, 1.0f);
     return vd_check_launch("vd_softmax_rows_f32_f16");
+}
+
+extern "C" int vd_softmax_rows_f32_f32(const float* s, float* p, int64_t rows, int n, float scale, hipStream_t stream) {
+    VD_REQUIRE(s && p && rows > 0 && n > 0, "vd_softmax_rows_f32_f32: bad arguments");
+    VD_REQUIRE(rows < (1ll << 31), "vd_softmax_rows_f32_f32: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, stream, s, p, n, scale);
+    return vd_check_launch("vd_softmax_rows_f32_f32");
 }

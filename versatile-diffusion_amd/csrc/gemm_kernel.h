@@ -96,6 +96,7 @@ __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
 __device__ __forceinline__ float apply_act(int act, float v) {
     if (act == VD_ACT_QUICK_GELU) return vd_quick_gelu(v);
     if (act == VD_ACT_SILU) return vd_silu(v);
+    if (act == VD_ACT_GELU_TANH) return vd_gelu_tanh(v);
     return v;
 }
 

@@ -54,6 +54,12 @@ __device__ __forceinline__ float vd_erf(float x) {
 }
 // erf-form GELU (reference: F.gelu default, lib/model_zoo/attention.py:44)
 __device__ __forceinline__ float vd_gelu_erf(float x) { return 0.5f * x * (1.0f + vd_erf(x * 0.70710678118654752440f)); }
+// tanh-form GELU of the GPT-2 MLP (reference lib/model_zoo/optimus_models/optimus_gpt2.py:99-100); tanh(u) = 1 - 2 / (e^{2u} + 1)
+__device__ __forceinline__ float vd_gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+    return 0.5f * x * (1.0f + t);
+}
 // quick GELU used by the HF CLIP towers (x * sigmoid(1.702 x))
 __device__ __forceinline__ float vd_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 

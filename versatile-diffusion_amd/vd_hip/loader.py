@@ -45,6 +45,7 @@ PROTOTYPES = {
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vd_attention_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P]),
     "vd_softmax_rows_f32_f16": (_I, [_P, _P, _L, _I, _P]),
+    "vd_softmax_rows_f32_f32": (_I, [_P, _P, _L, _I, _F, _P]),
     "vd_timestep_embedding_f16": (_I, [_P, _P, _I, _I, _F, _P]),
     "vd_cfg_ddim_step_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
     "vd_cfg_ddim_step_dev_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),

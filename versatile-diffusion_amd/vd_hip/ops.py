@@ -13,7 +13,7 @@ import torch
 from .loader import VdGemmDesc, VdHipError, lib
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD = 1, 2, 4, 8, 16, 32
-ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 _ws_cache = {}
 
@@ -263,7 +263,7 @@ def attention(q, k, v, heads, *, scale=None, causal=False, out=None):
     with _Timed(("attn_fwd_kernel<%d>" % D) + ((" Nq=%d Nk=%d B=%d" % (Nq, Nk, B)) if PROFILE_SHAPES else ""), 4.0 * B * Nq * Nk * C, 2.0 * B * C * (2 * Nq + 2 * Nk)):
         _check(lib().vd_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, q.stride(1), k.stride(1),
                                       v.stride(1), out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                      float(scale), 1 if causal else 0, _stream()))
+                                      float(scale), int(causal), _stream()))
     return out
 
 
@@ -274,6 +274,15 @@ def softmax_rows(s, out=None):
     if out is None:
         out = torch.empty(s.shape, dtype=torch.float16, device=s.device)
     _check(lib().vd_softmax_rows_f32_f16(_ptr(s), _ptr(out), rows, n, _stream()))
+    return out
+
+
+def softmax_rows_f32(s, scale=1.0):
+    """softmax(scale * s) over the last dim, fp32 in / fp32 out."""
+    _req(s, "s", torch.float32)
+    n = s.shape[-1]
+    out = torch.empty_like(s)
+    _check(lib().vd_softmax_rows_f32_f32(_ptr(s), _ptr(out), s.numel() // n, n, float(scale), _stream()))
     return out
 
 
@@ -516,7 +525,7 @@ def _guarded(fn):
     return wrapper
 
 
-for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows",
+for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
               "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
