@@ -102,6 +102,12 @@ int vd_gemm_num_configs(void);
 /* Development hook (tools/gemm_sweep.py, A/B runs): force every following vd_gemm_f16 of this process onto tile_cfg
  * (-1 = planner's choice) where the shape permits.  Process-global and unsynchronised: not for production use. */
 int vd_gemm_set_override(int tile_cfg);
+/* Tuned launch table: a problem (M, N, K, ksize, epilogue class: bit 0 GEGLU, bit 1 LayerNorm fold, bit 2 two-source A) is
+ * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table
+ * (lib/gemm_tune.py) from a file tools/tune_forward.py measured inside a UNet forward -- the setting that decides, since
+ * weights then stream from HBM and activations come hot from the previous kernel.  Thread-safe. */
+int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
+int vd_gemm_tune_clear(void);
 
 /* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
  * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().

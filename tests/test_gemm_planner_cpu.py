@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
 T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
 T128x64d, T64x64d = 14, 15                                   # 3-stage ring for grids that do not fill the chip
 T128x128q, T128x128w8q, T128x320q, T128x160q = 16, 19, 20, 21   # 32-deep K tiles, 4-stage ring (>= 20 K tiles per block)
+T128x64w8, T256x256 = 4, 24
 
 
 def plan(M, N, K, ks=1, B=8, ws=True, act=0):
@@ -45,15 +46,17 @@ def test_wide_tile_for_the_64x64_level():
     for K, ks in ((2880, 3), (5760, 3), (1280, 1)):
         # >= 20 K tiles: 32-deep tiles in a 4-stage ring, and two 128x160 blocks per CU instead of one 128x320
         assert plan(32768, 320, K, ks=ks) == (T128x160q, 1)
-    assert plan(32768, 320, 320) == (T128x320, 1)             # 5 K tiles: 64-deep
-    assert plan(32768, 960, 320) == (T128x320, 1)
+    assert plan(32768, 320, 320) == (T128x64w8, 1)            # short K, many rows: small tiles, 4 waves per SIMD
+    assert plan(8192, 640, 640) == (T128x64w8, 1)
+    assert plan(32768, 960, 320) == (T128x320, 1)             # N > 640: the wide tile
     # 64 tiles of 128x320 would leave 3/4 of the CUs idle
     assert plan(8192, 640, 5760, ks=3)[0] not in (T128x320, T128x320q, T128x160q)
 
 
 def test_no_split_without_workspace_and_for_geglu():
     assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
-    assert plan(32768, 2560, 320, act=1) == (T128x128w8q, 1)   # VD_ACT_GEGLU = 1
+    assert plan(32768, 2560, 320, act=1) == (T256x256, 1)      # VD_ACT_GEGLU = 1; M >= 4096: the 256x256 tile
+    assert plan(2048, 10240, 1280, act=1) == (T128x128w8q, 1)
     assert plan(512, 10240, 1280, act=1) == (T128x128w8, 1)
 
 

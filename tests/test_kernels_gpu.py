@@ -333,6 +333,20 @@ def test_groupnorm(ops, dev, B, HW, c0, c1, silu, eps):
     assert rel_l2(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize("HW,C", [(4096, 320), (256, 1280), (64, 1280)])
+def test_groupnorm_large_mean_small_spread(ops, dev, HW, C):
+    """|mean| >> sigma with eps = 1e-6 (VAE / SpatialTransformer norms): a plain E[x^2] - mean^2 in fp32 loses the
+    variance to cancellation here; the kernels' shifted sums must match torch's two-pass statistics.  Covers the
+    partial + apply path (HW = 4096) and the single-launch slab path."""
+    g = torch.Generator().manual_seed(70 + HW)
+    x = (16.0 + 0.03 * torch.randn((2, HW, C), generator=g)).half().to(dev)   # fp16 spacing at 16 is 0.0156: the spread survives
+    gamma = rnd((C,), dev, 0.5, 71) + 1.0
+    beta = rnd((C,), dev, 0.5, 72)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-6).permute(0, 2, 1)
+    out = ops.groupnorm_silu(x, gamma, beta, groups=32, eps=1e-6, silu=False)
+    assert rel_l2(out, ref) < 3e-3
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 768), (513, 1280), (257, 1024), (5, 640)])
 def test_layernorm(ops, dev, rows, C):
     x = rnd((rows, C), dev, 2.0, 40) + 0.3

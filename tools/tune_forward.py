@@ -1,0 +1,146 @@
+"""In-forward autotuner of the GEMM launch table (dev tool, run on the MI355X box).
+
+    python tools/tune_forward.py [--workload t2i|i2v|dual|triple] [--batch B] [--out file.json] [--merge]
+
+For every distinct GEMM problem of one UNet forward at the workload's shape, every instantiation of the kernel template
+(and, for the small-M deep-K problems, a few split-K factors) is installed for THAT problem only (vd_gemm_tune_set), the
+whole forward is run a few times, and the time of that problem's launches is read from the per-launch events.  Tuning
+inside the forward is the point: weights stream from HBM there and activations come hot out of the previous kernel,
+which ranks configurations differently from a back-to-back micro-benchmark of one shape (tools/gemm_sweep.py).
+Writes the winners -- only where they beat the cost model's choice by more than 3 % -- as configs/gemm_tune_gfx950.json
+entries {M, N, K, ks, cls, kernel, nsplit}."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
+os.environ.setdefault("VD_QUIET", "1")
+os.environ["VD_GEMM_TUNE"] = "0"          # start from the cost model
+import torch  # noqa: E402
+import bench  # noqa: E402
+from vd_hip import ops  # noqa: E402
+from vd_hip.loader import lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="t2i")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--out", default=os.path.join(ROOT, "versatile-diffusion_amd", "configs", "gemm_tune_gfx950.json"))
+    ap.add_argument("--merge", action="store_true", help="keep the entries already in --out for other shapes")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--min-gain", type=float, default=0.03)
+    args = ap.parse_args()
+    wl = bench.WORKLOADS[args.workload]
+    B = args.batch if args.batch is not None else (max(1, wl["batch"] // 8) if wl["global_fixed"] else wl["batch"])
+    dev = torch.device("cuda:0")
+    net = bench.build_model(dev)
+    x, t, cs = bench.forward_inputs(wl, B, dev)
+    h = lib()
+    ncfg = h.vd_gemm_num_configs()
+    names = [h.vd_gemm_config_name(i).decode() for i in range(ncfg)]
+
+    calls = []                      # (M, N, K, ks, cls) of every GEMM launch of a forward, in order
+    real_gemm = ops.gemm.__wrapped__ if hasattr(ops.gemm, "__wrapped__") else ops.gemm
+
+    def forward():
+        with torch.no_grad():
+            return bench.run_forward(net, x, t, cs)
+
+    def timed_forward(reps):
+        """-> {problem key: total ms of its launches per forward}"""
+        agg = {}
+        ops.PROFILE_SHAPES = True
+        for _ in range(reps):
+            ops.profile_begin()
+            forward()
+            for name, fl, by, ms in ops.profile_end():
+                if "gemm_f16_kernel" not in name:
+                    continue
+                agg[name.split(">", 1)[1].strip()] = agg.get(name.split(">", 1)[1].strip(), 0.0) + ms / reps
+        return agg
+
+    for _ in range(2):
+        forward()
+    base = timed_forward(args.reps)
+    # problem keys: "M=32768 N=320 K=2880 ks=3 cls=0" (+ " split=n" in the profile names)
+    recorded = {}
+    for name in base:
+        key = name.split(" split=")[0]
+        recorded[key] = recorded.get(key, 0) + 1
+    counts = {}
+    ops.profile_begin()
+    forward()
+    for name, fl, by, ms in ops.profile_end():
+        if "gemm_f16_kernel" in name:
+            key = name.split(">", 1)[1].strip().split(" split=")[0]
+            counts[key] = counts.get(key, 0) + 1
+    problems = []
+    for key, cnt in sorted(counts.items(), key=lambda kv: -kv[1]):
+        f = dict(kv.split("=") for kv in key.split())
+        problems.append(((int(f["M"]), int(f["N"]), int(f["K"]), int(f["ks"]), int(f["cls"])), cnt))
+    print("%d distinct GEMM problems, %d launches per forward" % (len(problems), sum(counts.values())))
+
+    def key_of(M, N, K, ks, cls):
+        return "M=%d N=%d K=%d ks=%d cls=%d" % (M, N, K, ks, cls)
+
+    def time_of(agg, M, N, K, ks, cls):
+        k0 = key_of(M, N, K, ks, cls) + " "
+        return sum(v for k, v in agg.items() if k.startswith(k0))
+
+    entries, total_gain = [], 0.0
+    for (M, N, K, ks, cls), cnt in problems:
+        if M < 96 or N < 96:
+            continue
+        t0 = time_of(base, M, N, K, ks, cls)
+        if t0 <= 0:
+            continue
+        best = (t0, None, None)
+        splits = [1]
+        if M <= 2048 and K >= 2048 and not (cls & 3):
+            splits = [1, 2, 3, 4, 6, 8, 12]
+        for c in range(ncfg):
+            bm, bn = [int(v) for v in names[c].split("<")[1].split(",")[:2]]
+            if (cls & 1) and bn % 128 != 0:
+                continue
+            tiles = -(-M // bm) * -(-N // bn)
+            for sp in splits:
+                if sp > 1 and K // 64 // sp < 8:
+                    continue
+                if tiles * sp < 48:
+                    continue
+                h.vd_gemm_tune_clear()
+                h.vd_gemm_tune_set(M, N, K, ks, cls, c, sp)
+                try:
+                    forward()
+                    tt = time_of(timed_forward(args.reps), M, N, K, ks, cls)
+                except Exception as e:  # noqa
+                    continue
+                if 0 < tt < best[0]:
+                    best = (tt, c, sp)
+        h.vd_gemm_tune_clear()
+        gain = (t0 - best[0]) / t0
+        print("%-40s x%-3d cost-model %7.1f us -> %-44s split %s %7.1f us (%+.1f %%)" % (
+            key_of(M, N, K, ks, cls), cnt, 1e3 * t0, names[best[1]] if best[1] is not None else "(kept)",
+            best[2], 1e3 * best[0], -100 * gain))
+        sys.stdout.flush()
+        if best[1] is not None and gain > args.min_gain:
+            entries.append({"M": M, "N": N, "K": K, "ks": ks, "cls": cls, "kernel": names[best[1]], "nsplit": best[2],
+                            "us_model": round(1e3 * t0, 1), "us_tuned": round(1e3 * best[0], 1), "launches": cnt})
+            total_gain += t0 - best[0]
+    print("sum of per-problem gains: %.3f ms per forward" % total_gain)
+    out = {"device": "MI355X (gfx950)", "tool": "tools/tune_forward.py", "entries": entries}
+    if args.merge and os.path.exists(args.out):
+        old = json.load(open(args.out))
+        keyf = lambda e: (e["M"], e["N"], e["K"], e["ks"], e["cls"])
+        have = {keyf(e) for e in entries}
+        out["entries"] = entries + [e for e in old.get("entries", []) if keyf(e) not in have]
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote %d entries to %s" % (len(out["entries"]), args.out))
+
+
+if __name__ == "__main__":
+    main()

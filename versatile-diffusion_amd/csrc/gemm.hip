@@ -1,6 +1,8 @@
 // vd_gemm_f16: validation, launch planner, the two-waves-per-SIMD instances of the kernel template in
 // gemm_kernel.h and the split-K reduce kernel.  (One-wave-per-SIMD instances: gemm_big.hip.)
 #include "gemm_kernel.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -66,7 +68,8 @@ enum TileCfg {
     T128x320b = 8, T128x256b = 9, T256x128b = 10, T128x160 = 11, T128x320b32 = 12, T128x128d = 13, T128x64d = 14, T64x64d = 15,
     // 32-deep K tiles, 4-stage ring (same LDS footprint as 64-deep / 2 stages, tiles issued 3 ahead instead of 1)
     T128x128q = 16, T128x64q = 17, T64x64q = 18, T128x128w8q = 19, T128x320q = 20, T128x160q = 21,
-    T_COUNT = 22
+    T256x320 = 22, T256x320q = 23, T256x256 = 24,
+    T_COUNT = 25
 };
 struct CfgInfo { int bm, bn; const char* name; };
 const CfgInfo kCfg[T_COUNT] = {
@@ -80,9 +83,21 @@ const CfgInfo kCfg[T_COUNT] = {
     {128, 64, "gemm_f16_kernel<128,64,64,32,256,3,64>"},     {64, 64, "gemm_f16_kernel<64,64,32,32,256,3,64>"},
     {128, 128, "gemm_f16_kernel<128,128,64,64,256,4,32>"},   {128, 64, "gemm_f16_kernel<128,64,64,32,256,4,32>"},
     {64, 64, "gemm_f16_kernel<64,64,32,32,256,4,32>"},       {128, 128, "gemm_f16_kernel<128,128,32,64,512,4,32>"},
-    {128, 320, "gemm_f16_kernel<128,320,32,160,512,4,32>"},  {128, 160, "gemm_f16_kernel<128,160,32,160,256,4,32>"}};
+    {128, 320, "gemm_f16_kernel<128,320,32,160,512,4,32>"},  {128, 160, "gemm_f16_kernel<128,160,32,160,256,4,32>"},
+    {256, 320, "gemm_f16_kernel<256,320,64,160,512,2,64>"},  {256, 320, "gemm_f16_kernel<256,320,64,160,512,4,32>"},
+    {256, 256, "gemm_f16_kernel<256,256,64,128,512,2,64>"}};
 
 std::atomic<int> g_override{-1};
+
+// Tuned launch table: (M, N, K, ksize, epilogue class) -> (tile configuration, split-K), filled by the host from a file
+// measured INSIDE a UNet forward (tools/tune_forward.py -> lib/gemm_tune.py); shapes that are not in it go through the
+// cost model below.  Read-mostly: writers take the mutex, the planner reads under it (a handful of entries).
+struct TuneEntry { int M, N, K, ks, cls, cfg, nsplit; };
+std::mutex g_tune_mu;
+std::vector<TuneEntry> g_tune;
+inline int epi_class(const VdGemmDesc& d) {
+    return (d.act == VD_ACT_GEGLU ? 1 : 0) | ((d.flags & VD_EPI_LNFOLD) ? 2 : 0) | (d.a1 ? 4 : 0);
+}
 
 // validate + normalise the descriptor and pick tile shape / split factor
 int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) {
@@ -174,7 +189,11 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     };
     TileCfg cfg = T64x64;
     int nsplit = 1;
-    if (d.act == VD_ACT_GEGLU) cfg = T128x128w8;  // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others
+    if (d.act == VD_ACT_GEGLU) {
+        // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others.  From M = 4096 rows on, the 256x256 tile
+        // (64x128 per wave) wins by ~15 % inside a forward: the proj weights are re-read by half as many row panels
+        cfg = (d.M >= 4096 && d.N % 256 == 0) ? T256x256 : T128x128w8;
+    }
     else if (d.M < 96 || d.N < 96) {
         // small-M weight streaming (time-embedding MLPs, the 0-D text-latent flow: M = CFG batch, N x K up to 5120 x
         // 10240): 64x64 tiles, but split K until the grid covers the chip -- the weight matrix is the only traffic
@@ -186,6 +205,11 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
             const float t = model_us(cands[2], ns);
             if (t < best) { best = t; nsplit = ns; }
         }
+    } else if (a.kt_total < 20 && d.M >= 4096 && d.N <= 640 && !lnfold) {
+        // short-K projections of the high-resolution levels (K = 320 .. 1280 against 8192+ rows): output-write bound and
+        // short-lived blocks -- 128x64 tiles on 8 waves (4 waves per SIMD, 4+ blocks per CU at different phases) beat the
+        // large tiles by 7-24 % inside a forward
+        cfg = T128x64w8;
     } else {
         float best = 1e30f;
         const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1);
@@ -196,12 +220,26 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
                 if (t < best) { best = t; cfg = c.cfg; nsplit = ns; }
             }
     }
+    bool tuned = false;
+    if (d.split_k <= 0) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        const int cls = epi_class(d);
+        for (const TuneEntry& t : g_tune)
+            if (t.M == d.M && t.N == d.N && t.K == d.K && t.ks == d.ksize && t.cls == cls && d.batch == 1) {
+                if (t.nsplit > 1 && !can_split) break;
+                if (d.act == VD_ACT_GEGLU && kCfg[t.cfg].bn % 128 != 0) break;
+                cfg = (TileCfg)t.cfg;
+                nsplit = t.nsplit > 0 ? t.nsplit : 1;
+                tuned = true;
+                break;
+            }
+    }
     {   // developer override (vd_gemm_set_override / VD_GEMM_TILE=<n>): never set in production runs
         static const char* ov_env = getenv("VD_GEMM_TILE");
         int ov = g_override.load(std::memory_order_relaxed);
         if (ov < 0 && ov_env) ov = atoi(ov_env);
         const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T256x128 || ov == T128x256 || ov == T128x256b || ov == T128x128d ||
-                              ov == T128x128q || ov == T128x128w8q;
+                              ov == T128x128q || ov == T128x128w8q || ov == T256x256;
         if (ov >= 0 && ov < T_COUNT && (d.act != VD_ACT_GEGLU || geglu_ok) && !(d.M < 96 || d.N < 96)) {
             cfg = (TileCfg)ov;
             // re-plan the split for the forced tile: fill the chip once (one block per CU for the 1-block-per-CU tiles)
@@ -220,7 +258,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     }
     if (d.split_k > 0) nsplit = d.split_k;
     if (nsplit > a.kt_total) nsplit = a.kt_total;
-    if (g_override.load(std::memory_order_relaxed) < 0) {
+    if (g_override.load(std::memory_order_relaxed) < 0 && !tuned) {
         // Pipeline-depth variants of the chosen tile.  32-deep K tiles in a 4-stage ring (same LDS footprint as 64-deep
         // x 2, tiles issued 3 ahead instead of 1) win wherever a block streams >= ~20 K tiles: inside a UNet forward the
         // weights of every layer come from HBM (1.7 GB per forward against 256 MB of Infinity Cache) and one 64-deep tile
@@ -285,6 +323,23 @@ extern "C" const char* vd_gemm_config_name(int tile_cfg) {
     return (tile_cfg >= 0 && tile_cfg < T_COUNT) ? kCfg[tile_cfg].name : nullptr;
 }
 extern "C" int vd_gemm_num_configs(void) { return T_COUNT; }
+extern "C" int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_cls, int tile_cfg, int nsplit) {
+    VD_REQUIRE(tile_cfg >= 0 && tile_cfg < T_COUNT && nsplit >= 0 && nsplit <= VD_MAX_SPLIT_K, "vd_gemm_tune_set: bad entry");
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    for (TuneEntry& t : g_tune)
+        if (t.M == M && t.N == N && t.K == K && t.ks == (ksize > 0 ? ksize : 1) && t.cls == epi_cls) {
+            t.cfg = tile_cfg;
+            t.nsplit = nsplit;
+            return VD_OK;
+        }
+    g_tune.push_back({M, N, K, ksize > 0 ? ksize : 1, epi_cls, tile_cfg, nsplit});
+    return VD_OK;
+}
+extern "C" int vd_gemm_tune_clear(void) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune.clear();
+    return VD_OK;
+}
 extern "C" int vd_gemm_set_override(int tile_cfg) {
     g_override.store(tile_cfg, std::memory_order_relaxed);
     return VD_OK;

@@ -14,6 +14,11 @@ int vd_gemm_launch_big(int cfg, int variant, const void* args, int nsplit, hipSt
         case 9: return launch_cfg<128, 256, 64, 128, 256, 3, 64, 1>(a, nsplit, stream);
         case 10: return launch_cfg<256, 128, 128, 64, 256, 3, 64, 1>(a, nsplit, stream);
         case 12: return launch_cfg<128, 320, 64, 160, 256, 4, 32, 1>(a, nsplit, stream);
+        // 8 waves, two per SIMD, 64x160 / 64x128 wave tiles (single fragment set): the largest tiles the register file
+        // and LDS admit -- half the L2->LDS and LDS->register traffic per FLOP of the 128x160 / 128x128 tiles
+        case 22: return launch_cfg<256, 320, 64, 160, 512, 2, 64, 2>(a, nsplit, stream);
+        case 23: return launch_cfg<256, 320, 64, 160, 512, 4, 32, 2>(a, nsplit, stream);
+        case 24: return launch_cfg<256, 256, 64, 128, 512, 2, 64, 2>(a, nsplit, stream);
         default:
             vd_set_error("vd_gemm_f16: unknown tile configuration %d", cfg);
             return VD_ERR_ARG;

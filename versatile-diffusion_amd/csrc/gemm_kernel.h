@@ -166,8 +166,10 @@ __device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, fl
 // The residual OR the per-batch row vector of a segment (the usual case: a layer has one of them) is requested for ALL
 // of a thread's segments before the accumulators are staged (epi_prefetch), so that latency overlaps part 1; a layer
 // with both reads the row vector in line.
-template <int BM, int CH, int NT, int MAX_CH>
-__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int out_n0, int tid, uint4* pre) {
+// ROWS rows of the LDS tile belong to one epilogue pass; row r of the pass is tile row (r / SEG) * WM + row0 + r % SEG
+// (SEG consecutive rows per wave-row; one pass: SEG = WM, row0 = 0 -> the identity).
+template <int ROWS, int CH, int NT, int MAX_CH, int SEG, int WM>
+__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, uint4* pre) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0);
     const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
     const bool want_rv = !want_res && (e.flags & VD_EPI_ROWVEC) != 0;
@@ -175,9 +177,9 @@ __device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int
     for (int k = 0; k < MAX_CH; ++k) {
         pre[k] = make_uint4(0, 0, 0, 0);
         const int c = tid + k * NT;
-        if (vec_ok && c < BM * CH) {
+        if (vec_ok && c < ROWS * CH) {
             const int r = c / CH, cc = (c % CH) * 8;
-            const int row = m0 + r, col = out_n0 + cc;
+            const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
             if (row < M && col + 8 <= e.N) {
                 if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
                 else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
@@ -186,17 +188,17 @@ __device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int
     }
 }
 
-template <int BM, int CH, int NT, int MAX_CH, int CS_LD>
-__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int out_n0, int tid, const f16* cs, const uint4* pre,
+template <int ROWS, int CH, int NT, int MAX_CH, int CS_LD, int SEG, int WM>
+__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, const f16* cs, const uint4* pre,
                                              bool nt) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
     const bool both = (e.flags & VD_EPI_RESIDUAL) && (e.flags & VD_EPI_ROWVEC);
 #pragma unroll
     for (int k = 0; k < MAX_CH; ++k) {
         const int c = tid + k * NT;
-        if (c < BM * CH) {
+        if (c < ROWS * CH) {
             const int r = c / CH, cc = (c % CH) * 8;
-            const int row = m0 + r, col = out_n0 + cc;
+            const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
             if (row < M && col < e.N) {
                 U4H8 t;
                 t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
@@ -208,8 +210,7 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + (float)b.e[i]);
                     // nt: streaming output that does not evict the weight / activation panels the other tiles of this
-                    // XCD keep re-reading from its 4 MiB L2 -- but then the NEXT kernel finds its input in HBM, not in
-                    // L2 / Infinity Cache; the host decides per launch (GemmArgs.nt_store)
+                    // XCD keep re-reading from its 4 MiB L2; the host decides per launch (GemmArgs.nt_store)
                     f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
                     if (nt) vd_store16_nt(dst, o.u);
                     else *reinterpret_cast<uint4*>(dst) = o.u;
@@ -232,6 +233,9 @@ __device__ __forceinline__ void wait_vm() {
 
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC>
 __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
+    // wave tiles of 8+ MFMA tiles at two waves per SIMD (256 registers each) cannot hold two fragment sets next to the
+    // accumulators: those instances read the fragments of a k-step right before its MFMAs (the partner wave covers the wait)
+    constexpr int FB = ((WM / 32) * (WN / 32) >= 8 && OCC >= 2) ? 1 : 2;
     static_assert(KB == 64 || KB == 32, "K tile depth");
     static_assert(STAGES >= 2, "LDS ring needs at least two stages");
     constexpr int KROW_BYTES = KB * 2;  // one LDS row of a stage
@@ -251,7 +255,10 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     constexpr int LPT = A_PASSES + B_PASSES;  // DMA pieces per thread and tile
     constexpr int STAGE_BYTES = (BMP + BNP) * KROW_BYTES;
     constexpr int CS_LD = BN + 8;  // fp16 epilogue tile leading dimension (halfs); row stride = odd multiple of 16 B
-    constexpr int EPI_BYTES = BM * CS_LD * 2;
+    // the epilogue tile goes through LDS in EP passes of BM / EP rows (2 where the whole tile would not fit: 256 x 320)
+    constexpr int EP = (BM * CS_LD * 2 + BM * 8 > 160 * 1024) ? 2 : 1;
+    static_assert((WM / 32) % EP == 0, "epilogue passes must divide the wave tile's 32-row blocks");
+    constexpr int EPI_BYTES = (BM / EP) * CS_LD * 2;
     constexpr int D = STAGES - 1;  // prefetch distance in tiles
     // the pieces of the tile issued in an iteration go into its first PSTEPS k-steps (the last step holds the wait)
     constexpr int PSTEPS = KS > 2 ? KS - 2 : 1;
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         rd_a[ks] = lds_off_kb<KB>(wm * WM + l31, ks * 2 + hi);
         rd_b[ks] = BMP * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
     }
-    f16x8 fa[2][MI], fb[2][NI];  // double-buffered operand fragments; indices are compile-time after unrolling
+    f16x8 fa[FB][MI], fb[FB][NI];  // (double-buffered) operand fragments; indices are compile-time after unrolling
     auto read_frags = [&](const char* st, int ks, f16x8* a, f16x8* b) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -444,6 +451,36 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         const char* st = smem + cbuf * STAGE_BYTES;
         if constexpr (MODE == 0) issue_begin(kt0 + i + D, ibuf);
         if (lnf) ln_accumulate(st);
+        if constexpr (FB == 1) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                read_frags(st, ks, fa[0], fb[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    if constexpr (MODE == 0) {
+                        if (ks < PSTEPS) {
+#pragma unroll
+                            for (int q = 0; q < PPS; ++q)
+                                if ((q * NMF) / PPS == m && ks * PPS + q < LPT) {
+                                    issue_piece(ks * PPS + q);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                        }
+                    }
+                    const int mi = m / NI, nj = m % NI;
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][nj], fa[0][mi], acc[mi][nj], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (MODE != 2) {
+                if constexpr (MODE == 0) wait_vm<LPT * (D - 1)>();
+                else wait_vm<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
@@ -479,6 +516,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);  // the MFMAs of this step stay in front of the next step's wait / barrier
         }
+        }  // FB == 2
     };
 
     // ---- prologue: the first D tiles in one burst, then the fragments of k-step 0 of tile 0
@@ -494,7 +532,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        read_frags(smem, 0, fa[0], fb[0]);
+        if constexpr (FB == 2) read_frags(smem, 0, fa[0], fb[0]);
         int cbuf = 0, ibuf = D % STAGES;
         int i = 0;
         auto next = [](int b) { return b + 1 == STAGES ? 0 : b + 1; };
@@ -585,19 +623,27 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 
     // residual / row-vector segments of part 2 are requested NOW so their latency overlaps part 1 (the block is
     // short-lived on the K = 320..1280 projections: every serial memory round trip shows)
-    constexpr int MAX_CH = BM * (BN / 8) / NT;
-    uint4 pre[MAX_CH];
-    if (geglu) epi_prefetch<BM, BN / 16, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre);
-    else epi_prefetch<BM, BN / 8, NT, MAX_CH>(e, d.M, m0, out_n0, tid, pre);
+    constexpr int MIP = MI / EP;          // 32-row blocks of a wave tile per pass
+    constexpr int SEG = MIP * 32;         // consecutive tile rows per wave-row in one pass
+    constexpr int PROWS = BM / EP;        // rows of the LDS tile
+    constexpr int MAX_CH = PROWS * (BN / 8) / NT;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int lrow_c = wm * WM + i * 32 + l31;
-        const int row = m0 + lrow_c;
+    for (int ep = 0; ep < EP; ++ep) {
+    if (ep > 0) __syncthreads();  // the previous pass has left the LDS tile
+    uint4 pre[MAX_CH];
+    if (geglu) epi_prefetch<PROWS, BN / 16, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+    else epi_prefetch<PROWS, BN / 8, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+#pragma unroll
+    for (int ii = 0; ii < MIP; ++ii) {
+        const int i = ep * MIP + ii;
+        const int lrow_t = wm * WM + i * 32 + l31;        // row inside the block tile
+        const int lrow_c = wm * SEG + ii * 32 + l31;      // row inside this pass's LDS tile
+        const int row = m0 + lrow_t;
         float bm = 0.f;
         if ((e.flags & VD_EPI_BIAS) && (e.flags & VD_EPI_BIAS_ALONG_M) && row < d.M) bm = (float)e.bias[row];
         float ln_rstd = 1.f, ln_nmr = 0.f;  // y = rstd * acc - (mean * rstd) * colsum[n] + bias'[n]
         if (lnf) {
-            const float2 st = lnst[lrow_c];
+            const float2 st = lnst[lrow_t];
             ln_rstd = st.y;
             ln_nmr = -st.x * st.y;
         }
@@ -679,15 +725,17 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     __syncthreads();
 
     // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
-    if (geglu) epi_writeout<BM, BN / 16, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre, p.nt_store != 0);
-    else epi_writeout<BM, BN / 8, NT, MAX_CH, CS_LD>(e, d.M, m0, out_n0, tid, cs, pre, p.nt_store != 0);
+    if (geglu) epi_writeout<PROWS, BN / 16, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0);
+    else epi_writeout<PROWS, BN / 8, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0);
+    }  // epilogue pass
 }
 
 template <int BM, int BN, int NT, int STAGES, int KB>
 constexpr int gemm_lds_bytes() {
     constexpr int rpp = NT / (KB / 8);
     constexpr int stage = ((BM + rpp - 1) / rpp + (BN + rpp - 1) / rpp) * rpp * KB * 2 * STAGES;
-    constexpr int epi = BM * (BN + 8) * 2 + BM * 8;  // epilogue tile + LayerNorm-fold row statistics
+    constexpr int ep = (BM * (BN + 8) * 2 + BM * 8 > 160 * 1024) ? 2 : 1;
+    constexpr int epi = (BM / ep) * (BN + 8) * 2 + BM * 8;  // epilogue tile (one pass) + LayerNorm-fold row statistics
     return stage > epi ? stage : epi;
 }
 

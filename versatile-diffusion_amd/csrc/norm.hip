@@ -43,6 +43,14 @@ __device__ __forceinline__ const f16* gn_src(const f16* x0, int c0, const f16* x
     return (ch < c0) ? (x0 + row * c0 + ch) : (x1 + row * c1 + (ch - c0));
 }
 
+// One-pass variance with a per-group SHIFT: sums run over (x - k_g), k_g = the group's first sample (row 0, first channel
+// of the group).  Any sample lies within a few sigma of the mean, so sum((x-k)^2)/n - (sum(x-k)/n)^2 no longer cancels
+// catastrophically when |mean| >> sigma (a plain E[x^2] - mean^2 in fp32 collapses to var = 0 there, which matters with
+// eps = 1e-6 in the VAE / SpatialTransformer norms); torch's two-pass / Welford form has the same robustness.
+__device__ __forceinline__ float gn_shift(const f16* x0, int c0, const f16* x1, int c1, size_t row0, int group, int cg) {
+    return (float)*gn_src(x0, c0, x1, c1, row0, group * cg);
+}
+
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, const f16* x1, int c1, float* part,
                                                          int HW, int groups, GnGeom g) {
     __shared__ float ls[64 * 2];
@@ -58,9 +66,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
         for (int pos = 0; pos < g.npos; ++pos) {
             const int cc = tc + pos * g.TC;
             if (cc >= g.C8) break;
-            float s[8], q[8];
+            float s[8], q[8], kk[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+            for (int i = 0; i < 8; ++i) {
+                s[i] = q[i] = 0.f;
+                kk[i] = gn_shift(x0, c0, x1, c1, (size_t)b * HW, (cc * 8 + i) / cg, cg);
+            }
             // 4 rows per trip, all four 16-byte loads issued before any is consumed: with ~2 blocks per CU a single
             // load in flight per thread left HBM at a quarter of its bandwidth (rows past the slab are clamped and
             // weighted 0 rather than branched around, so the loads stay unconditional)
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
                 for (int u = 0; u < GN_U; ++u)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float v = (float)t[u].e[i] * wgt[u];
+                        const float v = ((float)t[u].e[i] - kk[i]) * wgt[u];
                         s[i] += v;
                         q[i] += v * v;
                     }
@@ -138,10 +149,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* x0, int c0, co
         }
         __syncthreads();
         if (tid < groups) {
-            const float mean = red[tid * 2] * inv_count;
-            float var = red[tid * 2 + 1] * inv_count - mean * mean;
+            const float ms = red[tid * 2] * inv_count;   // mean of (x - k)
+            float var = red[tid * 2 + 1] * inv_count - ms * ms;
             if (var < 0.f) var = 0.f;
-            stat[tid * 2] = mean;
+            stat[tid * 2] = ms + gn_shift(x0, c0, x1, c1, (size_t)b * HW, tid, g.C / groups);
             stat[tid * 2 + 1] = rsqrtf(var + eps);
         }
         __syncthreads();
@@ -233,14 +244,17 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
             wgt[u] = r < HW ? 1.f : 0.f;
             t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (r < HW ? r : HW - 1), ch));
         }
-        float sm[8], sq[8];
+        float sm[8], sq[8], kk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sm[i] = sq[i] = 0.f;
+        for (int i = 0; i < 8; ++i) {
+            sm[i] = sq[i] = 0.f;
+            kk[i] = gn_shift(x0, c0, x1, c1, (size_t)b * HW, (ch + i) / cg, cg);
+        }
 #pragma unroll
         for (int u = 0; u < NITEM; ++u)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float v = (float)t[u].e[i] * wgt[u];
+                const float v = ((float)t[u].e[i] - kk[i]) * wgt[u];
                 sm[i] += v;
                 sq[i] += v * v;
             }
@@ -263,10 +277,10 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
     }
     __syncthreads();
     if (tid < ngrp) {
-        const float mean = ls[tid * 2] * inv_count;
-        float var = ls[tid * 2 + 1] * inv_count - mean * mean;
+        const float ms = ls[tid * 2] * inv_count;
+        float var = ls[tid * 2 + 1] * inv_count - ms * ms;
         if (var < 0.f) var = 0.f;
-        stat[tid * 2] = mean;
+        stat[tid * 2] = ms + gn_shift(x0, c0, x1, c1, (size_t)b * HW, ch0 / cg + tid, cg);
         stat[tid * 2 + 1] = rsqrtf(var + eps);
     }
     __syncthreads();
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256) void gn0d_kernel(const f16* x0, int c0, const 
                 as = aq = 0.f;
                 gcur = gi;
             }
-            const float v = (float)t.e[k];
+            const float v = (float)t.e[k] - gn_shift(x0, c0, x1, c1, (size_t)b * S, gi, cg);
             as += v;
             aq += v * v;
         }
@@ -336,10 +350,10 @@ __global__ __launch_bounds__(256) void gn0d_kernel(const f16* x0, int c0, const 
     __syncthreads();
     if (tid < groups) {
         const float inv = 1.0f / ((float)S * (float)cg);
-        const float mean = ls[tid * 2] * inv;
-        float var = ls[tid * 2 + 1] * inv - mean * mean;
+        const float ms = ls[tid * 2] * inv;
+        float var = ls[tid * 2 + 1] * inv - ms * ms;
         if (var < 0.f) var = 0.f;
-        stat[tid * 2] = mean;
+        stat[tid * 2] = ms + gn_shift(x0, c0, x1, c1, (size_t)b * S, tid, cg);
         stat[tid * 2 + 1] = rsqrtf(var + eps);
     }
     __syncthreads();

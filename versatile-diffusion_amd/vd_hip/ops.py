@@ -16,6 +16,7 @@ EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD = 
 ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 _ws_cache = {}
+_tune_checked = [False]
 
 # ---- optional per-launch instrumentation (bench.py roofline leg; off in the product path) -------------
 _prof = None
@@ -117,6 +118,10 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
+    if not _tune_checked[0]:     # shipped tuned launch table (vd_hip/tune.py), installed on first use
+        _tune_checked[0] = True
+        from . import tune
+        tune.ensure_loaded()
     d = VdGemmDesc()
     if K is None:
         K = w.shape[-1]
@@ -176,8 +181,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         name = gemm_kernel_name(plan_cfg.value)
-        if PROFILE_SHAPES:
-            name += " M=%d N=%d K=%d ks=%d split=%d%s" % (M, N, K, d.ksize, plan_ns.value, " cat" if a1 is not None else "")
+        if PROFILE_SHAPES:   # cls: epilogue class of the tuned launch table (bit 0 GEGLU, 1 LayerNorm fold, 2 two-source A)
+            cls = (1 if act == ACT_GEGLU else 0) | (2 if colsum is not None else 0) | (4 if a1 is not None else 0)
+            name += " M=%d N=%d K=%d ks=%d cls=%d split=%d" % (M, N, K, max(int(d.ksize), 1), cls, plan_ns.value)
     nb = max(batch, 1)
     with _Timed(name, 2.0 * nb * M * N * K, 2.0 * nb * (M * K + N * K + M * n_out)):
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
