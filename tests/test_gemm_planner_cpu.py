@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
 
 T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
 T128x64d, T64x64d = 14, 15                                   # 3-stage ring for grids that do not fill the chip
-T128x128q, T128x128w8q, T128x320q, T128x160q = 16, 19, 20, 21   # 32-deep K tiles, 4-stage ring (>= 20 K tiles per block)
+T128x128q, T128x128w8q, T128x320q, T128x160q = 16, 19, 20, 21   # 32-deep K tiles, 4-stage ring: VD_GEMM_VARIANT=q|h only
 T128x64w8, T256x256 = 4, 24
 
 
@@ -36,7 +36,7 @@ def test_round_quantisation_drives_the_split():
     assert plan(2048, 1280, 11520, ks=3) == (T128x128, 3)
     assert plan(2048, 1280, 23040, ks=3) == (T128x128, 3)
     # 320 tiles already cover most of a round: no split
-    assert plan(8192, 640, 5760, ks=3) == (T128x128q, 1)
+    assert plan(8192, 640, 5760, ks=3) == (T128x128, 1)
     # 40 tiles at the 8x8 level: deep split
     cfg, ns = plan(512, 1280, 11520, ks=3)
     assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
@@ -44,8 +44,7 @@ def test_round_quantisation_drives_the_split():
 
 def test_wide_tile_for_the_64x64_level():
     for K, ks in ((2880, 3), (5760, 3), (1280, 1)):
-        # >= 20 K tiles: 32-deep tiles in a 4-stage ring, and two 128x160 blocks per CU instead of one 128x320
-        assert plan(32768, 320, K, ks=ks) == (T128x160q, 1)
+        assert plan(32768, 320, K, ks=ks) == (T128x320, 1)     # one block spans all of N: A is read from L2 once
     assert plan(32768, 320, 320) == (T128x64w8, 1)            # short K, many rows: small tiles, 4 waves per SIMD
     assert plan(8192, 640, 640) == (T128x64w8, 1)
     assert plan(32768, 960, 320) == (T128x320, 1)             # N > 640: the wide tile
@@ -56,8 +55,22 @@ def test_wide_tile_for_the_64x64_level():
 def test_no_split_without_workspace_and_for_geglu():
     assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
     assert plan(32768, 2560, 320, act=1) == (T256x256, 1)      # VD_ACT_GEGLU = 1; M >= 4096: the 256x256 tile
-    assert plan(2048, 10240, 1280, act=1) == (T128x128w8q, 1)
+    assert plan(2048, 10240, 1280, act=1) == (T128x128w8, 1)
     assert plan(512, 10240, 1280, act=1) == (T128x128w8, 1)
+
+
+def test_layernorm_fold_uses_fold_instances():
+    from vd_hip.loader import VdGemmDesc, lib
+    fold_ok = {T128x128, T128x64, T64x64, T128x128w8, T128x64w8, T128x320, T64x64d, T256x256}
+    for (M, N, K, act) in ((32768, 960, 320, 0), (32768, 2560, 320, 1), (512, 3840, 1280, 0), (2048, 1280, 1280, 0), (8, 1280, 320, 0)):
+        d = VdGemmDesc()
+        d.M, d.N, d.K, d.act = M, N, K, act
+        d.a0 = d.w = d.out = d.colsum = 16
+        d.flags = 32                                          # VD_EPI_LNFOLD
+        d.ln_eps = 1e-5
+        cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+        assert cfg.value in fold_ok and ns.value == 1, (M, N, K, cfg.value, ns.value)
 
 
 def test_small_m_weight_streaming_splits_k():

@@ -12,7 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libvd_hip.so")
+# VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
+OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
 SOURCES = ["gemm.hip", "gemm_big.hip", "norm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
@@ -43,10 +44,11 @@ def build(force=False, verbose=False):
             return OUT
         raise RuntimeError("hipcc not found at %s and no prebuilt libvd_hip.so" % hipcc)
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = os.path.join(HERE, "build", os.path.basename(OUT).replace(".so", "") if os.environ.get("VD_BUILD_OUT") else "")
+    os.makedirs(objdir, exist_ok=True)
     procs = []
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("VD_EXTRA_DEFS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))

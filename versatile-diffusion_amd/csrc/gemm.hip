@@ -259,29 +259,22 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     if (d.split_k > 0) nsplit = d.split_k;
     if (nsplit > a.kt_total) nsplit = a.kt_total;
     if (g_override.load(std::memory_order_relaxed) < 0 && !tuned) {
-        // Pipeline-depth variants of the chosen tile.  32-deep K tiles in a 4-stage ring (same LDS footprint as 64-deep
-        // x 2, tiles issued 3 ahead instead of 1) win wherever a block streams >= ~20 K tiles: inside a UNet forward the
-        // weights of every layer come from HBM (1.7 GB per forward against 256 MB of Infinity Cache) and one 64-deep tile
-        // of lead does not cover that latency (measured in-forward: 128x128 convs of the 32x32 level -14 %, 128x320
-        // -4..9 %, GEGLU -3..5 %; split-K shapes and the small tiles lose 3-10 % and keep 64-deep tiles).
-        // VD_GEMM_VARIANT=0 switches it off, =q forces it, =h also moves the short-K N = 320 layers to 128x160 blocks
-        // (development A/B runs).
+        // Pipeline-depth variants: 32-deep K tiles in a 4-stage ring ("q" instances: same LDS footprint as 64-deep x 2,
+        // tiles issued 3 ahead) and two 128x160 blocks per CU for the N = 320 layers.  Both won 1-3 % over the forward under
+        // the software-pipelined main loop and LOSE 2 % under the default burst loop (same box: 13.15 vs 13.00 ms), so
+        // they are development switches only: VD_GEMM_VARIANT=q forces the q instances, =h also the 128x160 blocks.
         static const char* var_env = getenv("VD_GEMM_VARIANT");
-        const char v = var_env ? var_env[0] : 'a';
+        const char v = var_env ? var_env[0] : '0';
         const int ktps = (a.kt_total + nsplit - 1) / nsplit;
-        const bool deep_k = ktps >= 20 && nsplit == 1;
-        // N = 320 / 640 / 960 layers of the 64x64 level: two independent 4-wave blocks of 128x160 per CU beat one 8-wave
-        // block of 128x320 by ~3 % over the forward although they fetch the activation panel twice -- the barrier
-        // groups are half as large and the two blocks drift out of phase (h = for every K, default = deep K only)
-        if ((v == 'h' || (v != '0' && deep_k)) && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
-        if (v == 'q' || (v != '0' && (cfg == T128x128w8 ? d.M >= 2048 : deep_k))) {
+        if (v == 'h' && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
+        if (v == 'q' || v == 'h') {
             switch (cfg) {
                 case T128x128: cfg = T128x128q; break;
                 case T128x128w8: cfg = T128x128w8q; break;
                 case T128x320: cfg = T128x320q; break;
                 case T128x160: cfg = T128x160q; break;
-                case T128x64: if (v == 'q') cfg = T128x64q; break;
-                case T64x64: if (v == 'q') cfg = T64x64q; break;
+                case T128x64: cfg = T128x64q; break;
+                case T64x64: cfg = T64x64q; break;
                 default: break;
             }
         }
@@ -290,6 +283,18 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         if (grid_blocks <= 400 && ktps >= 8) {
             if (cfg == T128x64) cfg = T128x64d;
             else if (cfg == T64x64) cfg = T64x64d;
+        }
+    }
+    if (lnfold) {
+        // the LayerNorm fold is a compile-time variant of the kernel, instantiated for these tiles only
+        switch (cfg) {
+            case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T64x64d: case T256x256: break;
+            case T128x64d: case T128x64q: cfg = T128x64; break;
+            case T64x64q: cfg = T64x64; break;
+            case T128x128q: case T128x128d: cfg = T128x128; break;
+            case T128x128w8q: cfg = T128x128w8; break;
+            case T128x320q: case T128x160: case T128x160q: case T128x320b: case T128x320b32: case T256x320: case T256x320q: cfg = T128x320; break;
+            default: cfg = (d.act == VD_ACT_GEGLU) ? T128x128w8 : T128x128; break;
         }
     }
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
@@ -354,6 +359,19 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    if (d.flags & VD_EPI_LNFOLD) {
+        switch (cfg) {
+            case T128x128: rc = launch_cfg<128, 128, 64, 64, 256, 2, 64, 2, true>(a, nsplit, stream); break;
+            case T128x64: rc = launch_cfg<128, 64, 64, 32, 256, 2, 64, 2, true>(a, nsplit, stream); break;
+            case T64x64: rc = launch_cfg<64, 64, 32, 32, 256, 2, 64, 2, true>(a, nsplit, stream); break;
+            case T64x64d: rc = launch_cfg<64, 64, 32, 32, 256, 3, 64, 2, true>(a, nsplit, stream); break;
+            case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512, 2, 64, 4, true>(a, nsplit, stream); break;
+            case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512, 2, 64, 4, true>(a, nsplit, stream); break;
+            case T128x320: rc = launch_cfg<128, 320, 32, 160, 512, 2, 64, 2, true>(a, nsplit, stream); break;
+            default: rc = vd_gemm_launch_big(cfg, 1, &a, nsplit, stream); break;   // 256x256 (GEGLU)
+        }
+        return rc;
+    }
     switch (cfg) {
         case T128x128: rc = launch_cfg<128, 128, 64, 64, 256, 2, 64, 2>(a, nsplit, stream); break;
         case T128x64: rc = launch_cfg<128, 64, 64, 32, 256, 2, 64, 2>(a, nsplit, stream); break;

@@ -8,7 +8,11 @@
 
 int vd_gemm_launch_big(int cfg, int variant, const void* args, int nsplit, hipStream_t stream) {
     const GemmArgs& a = *reinterpret_cast<const GemmArgs*>(args);
-    (void)variant;
+    if (variant == 1) {   // LayerNorm-fold instantiation
+        if (cfg == 24) return launch_cfg<256, 256, 64, 128, 512, 2, 64, 2, true>(a, nsplit, stream);
+        vd_set_error("vd_gemm_f16: no LayerNorm-fold instance of tile configuration %d", cfg);
+        return VD_ERR_ARG;
+    }
     switch (cfg) {
         case 8: return launch_cfg<128, 320, 64, 160, 256, 2, 64, 1>(a, nsplit, stream);
         case 9: return launch_cfg<128, 256, 64, 128, 256, 3, 64, 1>(a, nsplit, stream);

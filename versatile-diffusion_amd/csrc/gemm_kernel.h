@@ -231,7 +231,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
 __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     // wave tiles of 8+ MFMA tiles at two waves per SIMD (256 registers each) cannot hold two fragment sets next to the
     // accumulators: those instances read the fragments of a k-step right before its MFMAs (the partner wave covers the wait)
@@ -426,7 +426,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 
     // LayerNorm fold (VD_EPI_LNFOLD): row statistics of A are accumulated from the LDS-resident A tiles -- each thread
     // re-reads the 16 bytes per pass it DMA'd itself -- so the consumer GEMM needs no separate LayerNorm pass at all.
-    const bool lnf = (d.flags & VD_EPI_LNFOLD) != 0;
+    // LNF is a compile-time property of the instantiation: as a run-time flag the (never taken) branch in the K loop and
+    // the statistics registers cost every OTHER launch 1-2 % (0.2 ms per UNet forward, measured with the fold compiled out)
+    constexpr bool lnf = LNF;
     float ln_s[A_PASSES], ln_q[A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < A_PASSES; ++ps) ln_s[ps] = ln_q[ps] = 0.f;
@@ -519,6 +521,50 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         }  // FB == 2
     };
 
+#ifndef VD_GEMM_PIPELINED
+    // ---- main loop (default): every K tile = { wait for the tile, barrier, issue the tile D ahead as ONE burst, then the
+    // compiler-scheduled ds_read / MFMA stream of the landed tile }.  The burst gives a DMA the longest possible lead (a
+    // whole iteration per stage of distance), and hipcc's own interleave of the fragment reads with the MFMAs (fine
+    // lgkmcnt ladders) beats a hand-pinned order: the software-pipelined variant below (fragments double-buffered across
+    // the barrier, DMA pieces in the MFMA gaps, order pinned with sched_barrier) measured 4 % SLOWER over the UNet forward on
+    // the same box (13.50 vs 12.95 ms) although it wins by 3-4 % on a back-to-back micro-benchmark of one shape.
+    if (nk > 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < nk) {
+                issue_begin(kt0 + j, j);
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
+            }
+        int cbuf = 0, ibuf = D % STAGES;
+        for (int i = 0; i < nk; ++i) {
+            // tile i must have landed; in steady state the D-1 younger tiles stay in flight across the barrier
+            if (i + D - 1 < nk) wait_vm<LPT * (D - 1)>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
+            if (i + D < nk) {
+                issue_begin(kt0 + i + D, ibuf);
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
+            }
+            const char* st = smem + cbuf * STAGE_BYTES;
+            if (lnf) ln_accumulate(st);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 af[MI], bf[NI];
+                read_frags(st, ks, af, bf);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NI; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[nj], af[mi], acc[mi][nj], 0, 0, 0);
+            }
+            cbuf = (cbuf + 1 == STAGES) ? 0 : cbuf + 1;
+            ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
+        }
+    }
+#else
     // ---- prologue: the first D tiles in one burst, then the fragments of k-step 0 of tile 0
     if (nk > 0) {
 #pragma unroll
@@ -547,6 +593,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         }
         iteration(std::integral_constant<int, 2>{}, i, cbuf, 0, 0);
     }
+#endif
     __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
 
     const EpiCtx e = make_epi(d, z);
@@ -739,7 +786,7 @@ constexpr int gemm_lds_bytes() {
     return stage > epi ? stage : epi;
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>();
     static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
@@ -749,7 +796,7 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             vd_set_error("vd_gemm_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -758,7 +805,7 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
         done.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC>), grid, dim3(NT), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF>), grid, dim3(NT), LDS, stream, a);
     return vd_check_launch("vd_gemm_f16");
 }
 

@@ -51,6 +51,22 @@ __device__ __forceinline__ float gn_shift(const f16* x0, int c0, const f16* x1, 
     return (float)*gn_src(x0, c0, x1, c1, row0, group * cg);
 }
 
+// shifts of the 8 consecutive channels starting at ch (a multiple of 8): with cg >= 4 they span at most two groups, so two
+// loads serve all 8
+__device__ __forceinline__ void gn_shift8(float* kk, const f16* x0, int c0, const f16* x1, int c1, size_t row0, int ch, int cg) {
+    if (cg < 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = gn_shift(x0, c0, x1, c1, row0, (ch + i) / cg, cg);
+        return;
+    }
+    const int g_lo = ch / cg, g_hi = (ch + 7) / cg;
+    const float k_lo = gn_shift(x0, c0, x1, c1, row0, g_lo, cg);
+    const float k_hi = (g_hi == g_lo) ? k_lo : gn_shift(x0, c0, x1, c1, row0, g_hi, cg);
+    const int split = g_hi * cg - ch;   // first lane of the second group (>= 8 when there is none)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kk[i] = (g_hi != g_lo && i >= split) ? k_hi : k_lo;
+}
+
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, const f16* x1, int c1, float* part,
                                                          int HW, int groups, GnGeom g) {
     __shared__ float ls[64 * 2];
@@ -68,10 +84,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* x0, int c0, 
             if (cc >= g.C8) break;
             float s[8], q[8], kk[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s[i] = q[i] = 0.f;
-                kk[i] = gn_shift(x0, c0, x1, c1, (size_t)b * HW, (cc * 8 + i) / cg, cg);
-            }
+            for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+            gn_shift8(kk, x0, c0, x1, c1, (size_t)b * HW, cc * 8, cg);
             // 4 rows per trip, all four 16-byte loads issued before any is consumed: with ~2 blocks per CU a single
             // load in flight per thread left HBM at a quarter of its bandwidth (rows past the slab are clamped and
             // weighted 0 rather than branched around, so the loads stay unconditional)
@@ -246,10 +260,8 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
         }
         float sm[8], sq[8], kk[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            sm[i] = sq[i] = 0.f;
-            kk[i] = gn_shift(x0, c0, x1, c1, (size_t)b * HW, (ch + i) / cg, cg);
-        }
+        for (int i = 0; i < 8; ++i) sm[i] = sq[i] = 0.f;
+        gn_shift8(kk, x0, c0, x1, c1, (size_t)b * HW, ch, cg);
 #pragma unroll
         for (int u = 0; u < NITEM; ++u)
 #pragma unroll

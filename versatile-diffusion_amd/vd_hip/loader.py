@@ -96,7 +96,12 @@ def lib():
     except OSError as e:  # e.g. no ROCm runtime on this host
         raise VdHipError("cannot load %s: %s" % (_LIB_PATH, e))
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(h, name)
+        try:
+            fn = getattr(h, name)
+        except AttributeError:
+            if os.environ.get("VD_HIP_LIB"):   # development A/B against an older build of the ABI: tolerate missing entry points
+                continue
+            raise VdHipError("%s does not export %s: rebuild it (python versatile-diffusion_amd/build.py --force)" % (_LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
     _lib = h

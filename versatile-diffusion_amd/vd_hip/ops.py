@@ -25,7 +25,10 @@ PROFILE_SHAPES = False
 
 def gemm_kernel_name(cfg):
     """Instantiation name of a planner tile configuration (vd_gemm_config_name)."""
-    n = lib().vd_gemm_config_name(int(cfg))
+    try:
+        n = lib().vd_gemm_config_name(int(cfg))
+    except AttributeError:   # older build loaded through VD_HIP_LIB (development A/B)
+        return "gemm_f16_kernel<cfg %d>" % int(cfg)
     return n.decode() if n else "gemm_f16_kernel<?>"
 
 
