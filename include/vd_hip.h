@@ -84,7 +84,12 @@ typedef struct VdGemmDesc {
     const float* colsum; /* VD_EPI_LNFOLD: fp32 [N] row sums of w                                */
     float ln_eps;        /* VD_EPI_LNFOLD: epsilon of the folded LayerNorm                       */
     int32_t reserved;
+    int32_t* sync;       /* optional split-K arrival counters: VD_GEMM_SYNC_INTS ints, ZERO before their first use and
+                          * private to the stream (launches on one stream are ordered; the kernel leaves them zero).  With
+                          * them the last-arriving block of each output tile sums the tile's fp32 slabs (in split order:
+                          * results stay run-to-run identical) and runs the fused epilogue itself -- no reduce launch.   */
 } VdGemmDesc;
+#define VD_GEMM_SYNC_INTS 16384
 
 /* Replaces nn.Conv2d / nn.Linear / torch.bmm call sites:
  *   lib/model_zoo/openaimodel.py:89-117 (Upsample), :133-159 (Downsample), :254-274 (ResBlock._forward)

@@ -243,6 +243,38 @@ def test_gemm_split_k(ops, dev, split):
     assert rel_l2(out2, ref) < 2e-3
 
 
+@pytest.mark.parametrize("shape", [(192, 320, 64 * 40, 5), (1000, 328, 64 * 24, 3), (2048, 1280, 64 * 90, 3), (130, 70, 64 * 33, 32)])
+def test_gemm_split_k_in_kernel_fixup_equals_reduce_kernel(ops, dev, shape):
+    """Arrival-counter split-K (last block of a tile sums the slabs) against the two-kernel path: same partial sums, same
+    order; the fused epilogue rounds to fp16 before the residual add where the reduce kernel stays in fp32, so the two agree
+    to fp16 rounding, and the in-kernel path is bit-identical from launch to launch (slabs are summed in split order whichever
+    block arrives last).  Ragged edge tiles, every 64-deep tile shape, repeated launches (the counters re-arm)."""
+    from vd_hip.loader import lib
+    M, N, K, split = shape
+    a, w = rnd((M, K), dev, 1.0, 31), rnd((N, K), dev, 0.03, 32)
+    bias, res = rnd((N,), dev, 0.5, 33), rnd((M, N), dev, 1.0, 34)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    try:
+        for cfg in (-1, 0, 1, 2, 3, 4, 7, 14, 15, 24):
+            ops.gemm_set_override(cfg)
+            two = ops.gemm(a, w, bias=bias, res=res, split_k=split, fixup=False)
+            assert rel_l2(two, ref) < 2e-3, cfg
+            first = None
+            for rep in range(4):
+                one = ops.gemm(a, w, bias=bias, res=res, split_k=split, fixup=True)
+                assert rel_l2(one, ref) < 2e-3 and rel_l2(one, two) < 1e-3, (cfg, rep)
+                first = one if first is None else first
+                assert torch.equal(one, first), (cfg, rep)
+    finally:
+        ops.gemm_set_override(-1)
+    assert int(ops.sync_counters(dev).abs().sum()) == 0
+    # batched
+    Bt = 3
+    ab, wb = rnd((Bt, 256, 64 * 16), dev, 1.0, 35), rnd((Bt, 192, 64 * 16), dev, 0.05, 36)
+    kw = dict(M=256, N=192, K=64 * 16, batch=Bt, strides=(256 * 64 * 16, 192 * 64 * 16, 256 * 192, 0), split_k=4)
+    assert rel_l2(ops.gemm(ab, wb, fixup=True, **kw), ops.gemm(ab, wb, fixup=False, **kw)) < 1e-3
+
+
 def test_gemm_batched_f32_and_bias_along_m(ops, dev):
     Bt, M, N, K = 3, 200, 136, 128
     a = rnd((Bt, M, K), dev, 1.0, 15)

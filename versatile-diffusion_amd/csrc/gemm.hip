@@ -56,9 +56,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
 }  // namespace
 
 extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
-    // upper bound for any split factor the heuristic may choose
+    // upper bound for any split factor (split_k = 0) and tile shape the planner may choose; with arrival counters the slabs
+    // are whole tiles (up to 256 x 320) in register order
     const size_t batch = d->batch > 0 ? d->batch : 1;
-    return batch * VD_MAX_SPLIT_K * (size_t)d->M * (size_t)d->N * sizeof(float);
+    const size_t ns = d->split_k > 0 ? (size_t)d->split_k : (size_t)VD_MAX_SPLIT_K;
+    const size_t m = d->sync ? (size_t)d->M + 255 : (size_t)d->M, n = d->sync ? (size_t)d->N + 319 : (size_t)d->N;
+    return batch * ns * m * n * sizeof(float);
 }
 
 namespace {
@@ -359,6 +362,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    if ((long)a.tiles_m * a.tiles_n * zb > VD_GEMM_SYNC_INTS) a.d.sync = nullptr;  // more tiles than counters: two-kernel path
     if (d.flags & VD_EPI_LNFOLD) {
         switch (cfg) {
             case T128x128: rc = launch_cfg<128, 128, 64, 64, 256, 2, 64, 2, true>(a, nsplit, stream); break;
@@ -394,7 +398,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         default: rc = vd_gemm_launch_big(cfg, 0, &a, nsplit, stream); break;
     }
     if (rc != VD_OK) return rc;
-    if (nsplit > 1) {
+    if (nsplit > 1 && a.d.sync == nullptr) {
         const size_t total = (size_t)d.M * ((d.N + 7) / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

@@ -598,8 +598,72 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 
     const EpiCtx e = make_epi(d, z);
 
-    // ---- split-K / fp32 output: straight from registers (4 consecutive floats per lane and group)
-    if (gridDim.y > 1 || (d.flags & VD_EPI_OUT_F32)) {
+    // ---- split-K with arrival counters: every block of a tile leaves its fp32 accumulators in the workspace in REGISTER
+    // order ([8-byte group][thread]: fully coalesced, no address arithmetic per element); the block that arrives last sums
+    // the slabs in split order (its own included, so the result does not depend on which block that is) and carries on
+    // into the fused epilogue.  Saves the reduce launch and its drain / fill between two kernels.
+    // Coherence: the blocks of a tile run on different XCDs, whose L2s are not coherent for plain accesses.  An agent-scope
+    // fence pair would write back and invalidate the whole L2 per block (measured: +80 us per launch); instead every slab
+    // access is itself an agent-scope relaxed atomic (sc1: write-through / read-through at the device coherence point),
+    // ordered against the arrival counter by s_waitcnt vmcnt(0) + the workgroup barrier.
+    if (gridDim.y > 1 && d.sync != nullptr) {
+        typedef unsigned long long u64;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int G2 = MI * NI * 8;                     // 8-byte groups per thread
+        const int nsplit = gridDim.y;
+        const size_t tile_id = ((size_t)z * p.tiles_m + tm) * p.tiles_n + tn;
+        u64* slab = reinterpret_cast<u64*>(d.ws) + tile_id * nsplit * (size_t)(G2 * NT);
+        u64* mine = slab + (size_t)split * (G2 * NT) + tid;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    __hip_atomic_store(mine + ((i * NI + j) * 8 + g) * NT,
+                                       __builtin_bit_cast(u64, f32x2{acc[i][j][g * 2], acc[i][j][g * 2 + 1]}),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's slab stores are acknowledged at device scope
+        __syncthreads();                                    // ... and every wave's
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int last = (__hip_atomic_fetch_add(&d.sync[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1) ? 1 : 0;
+            if (last)   // every block of the tile has arrived: re-arm for the next launch
+                __hip_atomic_store(&d.sync[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        const int last = *flag;
+        if (!last) return;
+        __syncthreads();                                    // flag has been read: the LDS is free for the epilogue tile
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+        const u64* src = slab + tid;
+        for (int s = 0; s < nsplit; ++s, src += G2 * NT) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    u64 v[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        v[g] = __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x2 f = __builtin_bit_cast(f32x2, v[g]);
+                        acc[i][j][g * 2] += f.x;
+                        acc[i][j][g * 2 + 1] += f.y;
+                    }
+                }
+        }
+    }
+
+    // ---- split-K (slabs for the reduce kernel) / fp32 output: straight from registers (4 consecutive floats per lane and group)
+    if ((gridDim.y > 1 && d.sync == nullptr) || (d.flags & VD_EPI_OUT_F32)) {
         const bool partial = gridDim.y > 1;
         float* base = partial ? d.ws + ((size_t)z * gridDim.y + split) * (size_t)d.M * d.N
                               : reinterpret_cast<float*>(e.out);

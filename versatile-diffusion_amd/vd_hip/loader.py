@@ -26,6 +26,7 @@ class VdGemmDesc(ctypes.Structure):
         ("stride_a", ctypes.c_int64), ("stride_w", ctypes.c_int64), ("stride_out", ctypes.c_int64),
         ("stride_res", ctypes.c_int64),
         ("colsum", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("sync", ctypes.c_void_p),
     ]
 
 

@@ -7,6 +7,7 @@ No arithmetic is done in torch here.
 import ctypes
 import functools
 import math
+import os
 
 import torch
 
@@ -104,6 +105,21 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
+SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
+FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
+
+
+def sync_counters(device):
+    """Split-K arrival counters of vd_gemm_f16 (VdGemmDesc.sync): zeroed once, left zero by every launch, one set per
+    stream.  Under graph capture the zero fill is captured with the graph's own buffer."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, "gemm_sync")
+    buf = _ws_cache.get(key)
+    if buf is None:
+        buf = torch.zeros(SYNC_INTS, dtype=torch.int32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 def drop_workspaces(stream_id):
     """Forget scratch buffers keyed to a (capture) stream; a captured graph keeps its own pool alive."""
     for k in [k for k in _ws_cache if k[1] == stream_id]:
@@ -112,12 +128,14 @@ def drop_workspaces(stream_id):
 
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
-         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0):
+         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
     colsum (fp32 [N]) + ln_eps: the rows of A are layer-normalised on the fly (VD_EPI_LNFOLD); w / bias are then the
     folded gamma (*) W and beta W^T + bias (hip_layers.fold_layernorm).
+    fixup=True: split-K slabs are summed by the last-arriving block of each tile (VdGemmDesc.sync) instead of the reduce
+    kernel; default from VD_GEMM_FIXUP (off: the in-kernel tail measured 0.2 ms per UNet forward slower than the launch).
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
@@ -179,8 +197,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         d.ws = None
         if plan_ns.value > 1:
-            d.ws = workspace(max(batch, 1) * plan_ns.value * M * N * 4, a0.device, "gemm").data_ptr()
             d.split_k = plan_ns.value
+            d.sync = sync_counters(a0.device).data_ptr() if (FIXUP_DEFAULT if fixup is None else fixup) else None
+            d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         name = gemm_kernel_name(plan_cfg.value)
