@@ -54,7 +54,7 @@ def test_wide_tile_for_the_64x64_level():
 
 def test_no_split_without_workspace_and_for_geglu():
     assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
-    assert plan(32768, 2560, 320, act=1) == (T256x256, 1)      # VD_ACT_GEGLU = 1; M >= 4096: the 256x256 tile
+    assert plan(32768, 2560, 320, act=1) == (T128x128w8, 1)    # VD_ACT_GEGLU = 1: 8 waves, value / gate tile pairs
     assert plan(2048, 10240, 1280, act=1) == (T128x128w8, 1)
     assert plan(512, 10240, 1280, act=1) == (T128x128w8, 1)
 

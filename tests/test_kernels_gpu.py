@@ -130,9 +130,9 @@ def test_gemm_rowvec_residual(ops, dev, M, N, rpb):
         ops.gemm(a, w, bias=bias, rowvec=rowvec, rows_per_batch=rpb, alpha=0.5)
 
 
-def test_gemm_geglu(ops, dev):
+@pytest.mark.parametrize("M,C", [(384, 320), (4096, 320), (8192 + 72, 64)])
+def test_gemm_geglu(ops, dev, M, C):
     from vd_hip.pack import pack_geglu
-    M, C = 384, 320
     x = rnd((M, C), dev, 1.0, 8)
     w = rnd((8 * C, C), dev, 0.05, 9)
     b = rnd((8 * C,), dev, 0.2, 10)
@@ -170,10 +170,10 @@ def test_gemm_layernorm_fold(ops, dev, M, K, N, offset):
     assert rel_l2(out, ref - b.float() - res.float()) < 3e-3
 
 
-def test_gemm_layernorm_fold_geglu(ops, dev):
+@pytest.mark.parametrize("M,C", [(1024, 320), (4096 + 40, 320)])
+def test_gemm_layernorm_fold_geglu(ops, dev, M, C):
     from lib.model_zoo.hip_layers import fold_layernorm
     from vd_hip.pack import pack_geglu
-    M, C = 1024, 320
     x = rnd((M, C), dev, 1.0, 56) + 0.4
     w = rnd((8 * C, C), dev, 0.05, 57)
     b = rnd((8 * C,), dev, 0.2, 58)
@@ -192,8 +192,10 @@ def test_gemm_layernorm_fold_geglu(ops, dev):
 
 def test_gemm_every_tile_configuration(ops, dev):
     """Every instantiation of the GEMM template (vd_gemm_set_override) on a conv with concat + row vector, a plain GEMM
-    with ragged M / N / K and bias + residual, a split-K problem and a LayerNorm-folded projection."""
+    with ragged M / N / K and bias + residual, a split-K problem, a LayerNorm-folded projection and a GEGLU projection
+    (tiles whose width is not a multiple of 128 columns cannot pair value / gate columns: the planner's choice runs)."""
     from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.pack import pack_geglu
     from vd_hip.loader import lib
     from vd_hip.pack import pack_conv_weight
     B, H, W, c0, c1, Co = 2, 16, 16, 128, 64, 384
@@ -211,6 +213,10 @@ def test_gemm_every_tile_configuration(ops, dev):
     ln = torch.nn.LayerNorm(K, eps=1e-5).to(dev)
     ref_ln = F.layer_norm(xl.float(), (K,), ln.weight.float(), ln.bias.float(), 1e-5) @ wl.float().t()
     wlp, blp, cs = fold_layernorm(wl, None, ln)
+    xg, wg, bg = rnd((600, 192), dev, 1.0, 74), rnd((1024, 192), dev, 0.05, 75), rnd((1024,), dev, 0.2, 76)
+    vg, gg = (xg.float() @ wg.float().t() + bg.float()).chunk(2, dim=-1)
+    ref_geglu = vg * F.gelu(gg)
+    wgp, bgp = pack_geglu(wg, bg)
     n = lib().vd_gemm_num_configs()
     assert n >= 8
     try:
@@ -225,6 +231,8 @@ def test_gemm_every_tile_configuration(ops, dev):
             assert rel_l2(out, ref_split) < 2e-3, name
             out = ops.gemm(xl, wlp, bias=blp, colsum=cs, ln_eps=1e-5)
             assert rel_l2(out, ref_ln) < 3e-3, name
+            out = ops.gemm(xg, wgp, bias=bgp, act=ops.ACT_GEGLU)
+            assert rel_l2(out, ref_geglu) < 2e-3, name
     finally:
         ops.gemm_set_override(-1)
 

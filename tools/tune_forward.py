@@ -6,7 +6,8 @@ For every distinct GEMM problem of one UNet forward at the workload's shape, eve
 (and, for the small-M deep-K problems, a few split-K factors) is installed for THAT problem only (vd_gemm_tune_set), the
 whole forward is run a few times, and the time of that problem's launches is read from the per-launch events.  Tuning
 inside the forward is the point: weights stream from HBM there and activations come hot out of the previous kernel,
-which ranks configurations differently from a back-to-back micro-benchmark of one shape (tools/gemm_sweep.py).
+which ranks configurations differently from a back-to-back micro-benchmark of one shape (tools/gemm_sweep.py).  Every
+candidate's forward output is compared with the cost-model forward (rel-L2 < 5e-3) before its time is accepted.
 Writes the winners -- only where they beat the cost model's choice by more than 3 % -- as configs/gemm_tune_gfx950.json
 entries {M, N, K, ks, cls, kernel, nsplit}."""
 import argparse
@@ -63,7 +64,8 @@ def main():
         return agg
 
     for _ in range(2):
-        forward()
+        ref_out = forward()
+    ref_out = ref_out.float().clone()
     base = timed_forward(args.reps)
     # problem keys: "M=32768 N=320 K=2880 ks=3 cls=0" (+ " split=n" in the profile names)
     recorded = {}
@@ -114,7 +116,13 @@ def main():
                 h.vd_gemm_tune_clear()
                 h.vd_gemm_tune_set(M, N, K, ks, cls, c, sp)
                 try:
-                    forward()
+                    out = forward().float()
+                    # a candidate only counts if the forward still computes the same thing (round 2 shipped a rule for a
+                    # tile whose GEGLU epilogue did nothing -- "faster" -- because this check was missing)
+                    err = float((out - ref_out).norm() / ref_out.norm())
+                    if not err < 5e-3:
+                        print("  REJECTED %s split %d for %s: forward differs by %.2e" % (names[c], sp, key_of(M, N, K, ks, cls), err))
+                        continue
                     tt = time_of(timed_forward(args.reps), M, N, K, ks, cls)
                 except Exception as e:  # noqa
                     continue

@@ -22,6 +22,12 @@ t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
 c = torch.randn(2 * B, L, 768, device=dev, dtype=torch.float16) * 0.5
 ci = {"type": "text", "c": c, "kv_cache": {}}
 mode = sys.argv[2] if len(sys.argv) > 2 else ""
+if os.environ.get("VD_FWD_TUNE"):   # "M,N,K,ks,cls,cfg,nsplit;..." pins single problems to an instantiation (A/B of planner rules)
+    from vd_hip.loader import lib
+    from vd_hip import tune
+    tune.ensure_loaded()
+    for ent in os.environ["VD_FWD_TUNE"].split(";"):
+        assert lib().vd_gemm_tune_set(*[int(v) for v in ent.split(",")]) == 0
 with torch.no_grad():
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         net.apply_model({"type": "image", "x": x}, t, ci)

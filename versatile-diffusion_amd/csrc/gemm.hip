@@ -193,9 +193,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
     TileCfg cfg = T64x64;
     int nsplit = 1;
     if (d.act == VD_ACT_GEGLU) {
-        // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others.  From M = 4096 rows on, the 256x256 tile
-        // (64x128 per wave) wins by ~15 % inside a forward: the proj weights are re-read by half as many row panels
-        cfg = (d.M >= 4096 && d.N % 256 == 0) ? T256x256 : T128x128w8;
+        // 8 waves: the erf-heavy epilogue of one wave overlaps MFMAs of others.  (The 256x256 tile, 64x128 per wave, is
+        // 1 % slower over the forward for the M >= 4096 GEGLU projections: 13.48 vs 13.36 ms, same box.)
+        cfg = T128x128w8;
     }
     else if (d.M < 96 || d.N < 96) {
         // small-M weight streaming (time-embedding MLPs, the 0-D text-latent flow: M = CFG batch, N x K up to 5120 x

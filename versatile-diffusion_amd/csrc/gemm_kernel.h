@@ -759,12 +759,15 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             ln_nmr = -st.x * st.y;
         }
         if (geglu) {
-            if constexpr (NI == 2) {
-                // weight rows are packed per 64-row group as [32 value rows | 32 gate rows]: j = 0 value, j = 1 gate
+            // weight rows are packed per 64-row group as [32 value rows | 32 gate rows]: of each pair of 32-column MFMA
+            // tiles of the wave, j = 2jj holds the values and j = 2jj + 1 the gates of output columns jj*32 ..
+            if constexpr (NI % 2 == 0) {
+#pragma unroll
+                for (int jj = 0; jj < NI / 2; ++jj)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int lc = wn * (WN / 2) + 8 * g + 4 * hi;     // column inside the block's output tile
-                    const int pn = n0 + wn * WN + 8 * g + 4 * hi;      // packed weight row of the value element
+                    const int lc = wn * (WN / 2) + jj * 32 + 8 * g + 4 * hi;   // column inside the block's output tile
+                    const int pn = n0 + wn * WN + jj * 64 + 8 * g + 4 * hi;    // packed weight row of the value element
                     U2H4 bv, bg, o;
                     bv.u = make_uint2(0, 0);
                     bg.u = make_uint2(0, 0);
@@ -780,8 +783,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     const float cva[4] = {cv.x, cv.y, cv.z, cv.w}, cga[4] = {cg.x, cg.y, cg.z, cg.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float v = fmaf(ln_rstd, acc[i][0][g * 4 + q], ln_nmr * cva[q]) + (float)bv.e[q];
-                        const float gt = fmaf(ln_rstd, acc[i][1][g * 4 + q], ln_nmr * cga[q]) + (float)bg.e[q];
+                        const float v = fmaf(ln_rstd, acc[i][2 * jj][g * 4 + q], ln_nmr * cva[q]) + (float)bv.e[q];
+                        const float gt = fmaf(ln_rstd, acc[i][2 * jj + 1][g * 4 + q], ln_nmr * cga[q]) + (float)bg.e[q];
                         o.e[q] = (f16)(v * vd_gelu_erf(gt) * e.alpha);
                     }
                     *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
