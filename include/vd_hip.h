@@ -193,6 +193,12 @@ int vd_diag_gaussian_sample_f16(const void* moments, const void* noise, void* z,
 /* out = a * x + b * y (context mixing helpers, vd.py:383-396) */
 int vd_axpby_f16(const void* x, const void* y, void* out, float a, float b, int64_t n, hipStream_t stream);
 
+/* out = f(x) element-wise (in place allowed): erf-GELU of BERT's intermediate layer and the tanh of its pooler in the
+ * Optimus encoder (lib/model_zoo/optimus_models/optimus_bert.py:139-150 `gelu`, :451-463 BertPooler). */
+#define VD_UNARY_GELU_ERF 0
+#define VD_UNARY_TANH 1
+int vd_unary_f16(const void* x, void* out, int op, int64_t n, hipStream_t stream);
+
 /* CLIP helpers (arithmetic of HF transformers CLIPModel as called from lib/model_zoo/clip.py) */
 int vd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int L, int C,
                         hipStream_t stream);

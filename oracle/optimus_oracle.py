@@ -65,3 +65,40 @@ def sample_sequence(sd, p, z, bos, eos, n_head, n_layer, max_length=30, temperat
             generated[0, -1] = eos
             break
     return generated[0]
+
+
+# ---- encode side: BERT with the latent head -------------------------------------------------------------------------------
+def gelu_erf(x):
+    """optimus_bert.py:122-128"""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def bert_forward(sd, p, input_ids, attention_mask, n_head, n_layer, eps=1e-12):
+    """BertForLatentConnector_XX.forward (optimus_bert.py:1393-1439) -> (sequence_output [B, L, H], pooled_output [B, H]).
+    sd keys under `p` (e.g. 'encoder'): embeddings.*, encoder.layer.i.*, pooler.dense.*, linear.weight."""
+    lin = lambda q, x: x @ sd[q + ".weight"].t() + sd[q + ".bias"]
+    ln = lambda q, x: F.layer_norm(x, (x.shape[-1],), sd[q + ".weight"], sd[q + ".bias"], eps)
+    B, L = input_ids.shape
+    e = p + ".embeddings"
+    h = sd[e + ".word_embeddings.weight"][input_ids] + sd[e + ".position_embeddings.weight"][torch.arange(L)][None] \
+        + sd[e + ".token_type_embeddings.weight"][torch.zeros_like(input_ids)]          # :158-172
+    h = ln(e + ".LayerNorm", h)
+    ext = (1.0 - attention_mask.float())[:, None, None, :] * -10000.0                   # :1404-1412
+    H = h.shape[-1]
+    D = H // n_head
+    sh = lambda a: a.view(B, L, n_head, D).permute(0, 2, 1, 3)
+    for i in range(n_layer):
+        b = "%s.encoder.layer.%d" % (p, i)
+        q, k, v = (sh(lin(b + ".attention.self." + n, h)) for n in ("query", "key", "value"))   # :200-227
+        w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(D) + ext, dim=-1)
+        a = torch.matmul(w, v).permute(0, 2, 1, 3).reshape(B, L, H)
+        h = ln(b + ".attention.output.LayerNorm", lin(b + ".attention.output.dense", a) + h)       # :236-247
+        f = gelu_erf(lin(b + ".intermediate.dense", h))                                             # :289-299
+        h = ln(b + ".output.LayerNorm", lin(b + ".output.dense", f) + h)                            # :302-313
+    pooled = torch.tanh(lin(p + ".pooler.dense", h[:, 0]))                                          # :364-375
+    return h, pooled
+
+
+def bert_latent_mu(sd, p, pooled):
+    """optimus.py:742-744: z_mu = first half of encoder.linear(pooled)"""
+    return (pooled @ sd[p + ".linear.weight"].t()).chunk(2, -1)[0]

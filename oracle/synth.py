@@ -26,7 +26,7 @@ def synth_tensor(name, shape, seed=0):
     g = _gen(seed, name)
     leaf = name.split(".")[-1]
     is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "layer_norm", "layernorm",
-                                      "layrnorm", "in_layers.0.", "out_layers.0.", "ln_"))
+                                      "layrnorm", "LayerNorm", "in_layers.0.", "out_layers.0.", "ln_"))
     if name.endswith("position_ids"):
         return torch.arange(shape[-1]).expand(shape).clone()
     if leaf == "logit_scale":

@@ -357,7 +357,10 @@ def test_conv3x3_concat_rowvec_residual(ops, dev):
 @pytest.mark.parametrize("B,HW,c0,c1,silu,eps", [(2, 4096, 320, 0, True, 1e-5), (2, 256, 1280, 1280, True, 1e-5),
                                                  (3, 1024, 640, 320, True, 1e-5), (1, 64, 1280, 0, False, 1e-6),
                                                  (1, 16384, 128, 0, True, 1e-6), (2, 4096, 320, 0, False, 1e-6),
-                                                 (1, 100, 256, 0, True, 1e-6), (1, 300, 1920, 0, True, 1e-5)])
+                                                 (1, 100, 256, 0, True, 1e-6), (1, 300, 1920, 0, True, 1e-5),
+                                                 # 5 / 6 / 2 channels per group: 8 consecutive channels span 3+ groups
+                                                 (1, 200, 160, 0, True, 1e-5), (2, 4096, 192, 0, True, 1e-5),
+                                                 (2, 4096, 160, 0, False, 1e-5), (1, 512, 64, 0, False, 1e-6)])
 def test_groupnorm(ops, dev, B, HW, c0, c1, silu, eps):
     x0 = rnd((B, HW, c0), dev, 2.0, 30) + 0.5
     x1 = rnd((B, HW, c1), dev, 1.0, 31) if c1 else None

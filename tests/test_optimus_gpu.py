@@ -1,5 +1,7 @@
-"""Optimus decode side on the HIP path (lib/model_zoo/optimus.py) against the fixture the reference's vendored GPT-2 latent
-connector produced (tests/golden/optimus_tiny.npz) and against the CPU oracle at full size (12 layers, vocab 50260)."""
+"""Optimus on the HIP path (lib/model_zoo/optimus.py): the decode side against the fixture the reference's vendored GPT-2
+latent connector produced (tests/golden/optimus_tiny.npz) and the CPU oracle at full size (12 layers, vocab 50260); the
+encode side against the fixture of the reference's BERT latent connector / optimus_vae_next.encode
+(tests/golden/optimus_bert_tiny.npz) and the oracle at bert-base size."""
 import json
 import os
 
@@ -81,7 +83,7 @@ def test_optimus_vae_decode_end_to_end(dev, tmp_path):
     dcfg = dict(vocab_size=259, n_positions=40, n_ctx=40, n_embd=128, n_layer=2, n_head=2, latent_size=64, hidden_size=128,
                 layer_norm_epsilon=1e-5, initializer_range=0.02)
     cfg = CfgDict(type="optimus_vae_next", args=CfgDict(
-        encoder=CfgDict(type="optimus_bert_connector", args=CfgDict(latent_size=64)),
+        encoder=CfgDict(type="optimus_bert_connector", args=CfgDict(config=_bert_meta()["config"], latent_size=64)),
         decoder=CfgDict(type="optimus_gpt2_connector", args=CfgDict(config=dcfg)),
         tokenizer_encoder=CfgDict(type="optimus_bert_tokenizer", args=CfgDict()),
         tokenizer_decoder=CfgDict(type="optimus_gpt2_tokenizer", args=CfgDict(vocab_file=str(tmp_path / "vocab.json"),
@@ -98,5 +100,85 @@ def test_optimus_vae_decode_end_to_end(dev, tmp_path):
     b = vae.decode(z)
     assert a == b and len(a) == 3 and all(isinstance(s, str) for s in a)
     assert all("<BOS>" not in s and "<EOS>" not in s for s in a)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):       # no BERT vocabulary configured: encode says so instead of guessing
         vae.encode(["a cat"])
+
+
+# ---- encode side ------------------------------------------------------------------------------------------------------------
+def _bert_meta():
+    return json.load(open(os.path.join(GOLD, "optimus_bert_tokenizer.json")))
+
+
+def _build_bert(cfg, seed, dev):
+    from lib.model_zoo.optimus import optimus_bert_connector
+    from oracle import synth
+    net = optimus_bert_connector(cfg, latent_size=cfg["latent_size"])
+    sd = synth.synth_state_dict({"encoder." + k: v for k, v in synth.shapes_of(net).items()}, seed)
+    net.load_state_dict({k[len("encoder."):]: v for k, v in sd.items()}, strict=True)
+    return net.half().to(dev), sd
+
+
+def test_tiny_bert_vs_reference_fixture(dev):
+    """Right-padded batch through the BERT latent connector: hidden states of ALL rows (padded query rows included),
+    pooled output and the latent mean against what the reference's BertForLatentConnector_XX produced."""
+    m = _bert_meta()
+    net, _ = _build_bert(m["config"], m["seed"], dev)
+    g = load_gold("optimus_bert_tiny.npz")
+    ids = torch.from_numpy(g["ids"]).long().to(dev)
+    seq, pooled = net(ids, attention_mask=(ids > 0).float())
+    assert seq.shape == g["seq"].shape and seq.dtype == torch.float16
+    assert rel_l2(seq, g["seq"]) < 5e-3 and rel_l2(pooled, g["pooled"]) < 5e-3
+    mu, logvar = net.latent_stats(pooled)
+    assert rel_l2(mu, g["mu"]) < 5e-3 and logvar.shape == mu.shape
+    # a mask that is not a prefix: same rows in another order give the same per-token results
+    perm = torch.tensor([4, 0, 9, 1, 2, 3, 5, 6, 7, 8, 10], device=dev)
+    ids1 = ids[1:2]
+    pos = torch.arange(11, device=dev)
+    seq_p, _ = net(ids1[:, perm], attention_mask=(ids1[:, perm] > 0).float(), position_ids=pos[perm][None])
+    assert rel_l2(seq_p[0], seq[1][perm]) < 2e-3
+
+
+def test_full_size_bert_vs_oracle(dev):
+    """bert-base-cased geometry of the VD checkpoint (12 layers, 768 wide, vocab 28996, latent 768), 3 sentences of
+    different lengths, against the fp32 CPU oracle."""
+    from oracle import optimus_oracle as OO
+    cfg = dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu", latent_size=768)
+    net, sd = _build_bert(cfg, 77, dev)
+    assert sum(p.numel() for p in net.parameters()) == 108310272 + 2 * 768 * 768    # bert-base-cased + the latent head
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 28996, (3, 40), generator=g)
+    ids[0, 0], ids[1, 23:], ids[2, 9:] = 101, 0, 0
+    with torch.no_grad():
+        seq_ref, pooled_ref = OO.bert_forward(sd, "encoder", ids, (ids > 0).float(), 12, 12)
+        mu_ref = OO.bert_latent_mu(sd, "encoder", pooled_ref)
+    seq, pooled = net(ids.to(dev), attention_mask=(ids > 0).float().to(dev))
+    assert rel_l2(seq, seq_ref) < 5e-3 and rel_l2(pooled, pooled_ref) < 5e-3
+    assert rel_l2(net.latent_stats(pooled)[0], mu_ref) < 5e-3
+
+
+def test_optimus_vae_encode_vs_reference_fixture(dev, tmp_path):
+    """optimus_vae_next.encode (reference optimus.py:729-744) end to end -- lower-casing, WordPiece, truncation to
+    max_length pieces, [CLS] / [SEP], zero padding, mask, BERT, latent mean -- against the z the REFERENCE's encode
+    returned for the same sentences (vocabulary reduced to the pieces in play, see test_oracle_golden.reduced_bert_vocab)."""
+    from lib.cfg_helper import CfgDict
+    from lib.model_zoo import get_model
+    from oracle import synth
+    from test_oracle_golden import reduced_bert_vocab
+    m = _bert_meta()
+    dcfg = dict(vocab_size=259, n_positions=40, n_ctx=40, n_embd=128, n_layer=2, n_head=2, latent_size=64, hidden_size=128,
+                layer_norm_epsilon=1e-5, initializer_range=0.02)
+    cfg = CfgDict(type="optimus_vae_next", args=CfgDict(
+        encoder=CfgDict(type="optimus_bert_connector", args=CfgDict(config=m["config"], latent_size=m["config"]["latent_size"])),
+        decoder=CfgDict(type="optimus_gpt2_connector", args=CfgDict(config=dcfg)),
+        tokenizer_encoder=CfgDict(type="optimus_bert_tokenizer", args=CfgDict(vocab_file=reduced_bert_vocab(str(tmp_path / "v.txt")),
+                                                                               do_lower_case=False, max_len=512)),
+        tokenizer_decoder=CfgDict(type="optimus_gpt2_tokenizer", args=CfgDict()),
+        args=CfgDict(latent_size=64)))
+    vae = get_model()(cfg, verbose=False)
+    synth.load_synth_(vae.encoder, m["seed"], prefix="encoder.")
+    vae = vae.half().to(dev)
+    z = vae.encode(m["texts"], max_length=m["max_length"])
+    ref = load_gold("optimus_bert_tiny.npz")["encode_z"]
+    assert z.shape == ref.shape and z.dtype == torch.float16
+    assert rel_l2(z, ref) < 5e-3

@@ -240,3 +240,75 @@ def test_gpt2_tokenizer_matches_reference():
         assert ids == c["ids"], c["text"]
         assert tok.decode(ids, clean_up_tokenization_spaces=True) == c["decoded"]
     assert tok.encode("<BOS> hello <EOS>") == tok.encode("<BOS>") + tok.encode("hello") + tok.encode("<EOS>")
+
+
+# ---- Optimus encode side (BERT) -----------------------------------------------------------------------------------------
+def _bert_meta():
+    return json.load(open(os.path.join(GOLD, "optimus_bert_tokenizer.json")))
+
+
+def reduced_bert_vocab(path):
+    """A vocabulary file holding exactly the pieces the golden cases use, at their published ids (every other line a
+    placeholder): greedy longest-match over a subset that contains the full vocabulary's matches finds the same pieces,
+    so the fixture texts tokenise identically without the 213 KB published file."""
+    m = _bert_meta()
+    tk = m["tokenizer"]
+    lines = ["[unused-%d]" % i for i in range(tk["len"])]
+    cls_id, sep_id, pad_id, unk_id = tk["special"]
+    lines[cls_id], lines[sep_id], lines[pad_id], lines[unk_id], lines[103] = "[CLS]", "[SEP]", "[PAD]", "[UNK]", "[MASK]"
+    for c in tk["cases"]:
+        for piece, i in zip(c["pieces"], c["ids"]):
+            lines[i] = piece
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+    return path
+
+
+def test_bert_oracle_vs_reference_fixture():
+    """oracle/optimus_oracle.py bert_forward / bert_latent_mu against outputs of the REFERENCE's vendored
+    BertForLatentConnector_XX on right-padded batches (oracle/gen_golden_optimus_bert.py), and the product module's
+    state-dict key layout against the reference's (the synthetic weights are addressed by those names)."""
+    from lib.model_zoo.optimus import optimus_bert_connector
+    from oracle import optimus_oracle as OO
+    m = _bert_meta()
+    cfg = m["config"]
+    net = optimus_bert_connector(cfg, latent_size=cfg["latent_size"])
+    sd = synth.synth_state_dict({"encoder." + k: v for k, v in synth.shapes_of(net).items()}, m["seed"])
+    g = load("optimus_bert_tiny.npz")
+    ids = T(g["ids"]).long()
+    seq, pooled = OO.bert_forward(sd, "encoder", ids, (ids > 0).float(), cfg["num_attention_heads"], cfg["num_hidden_layers"])
+    assert rel(seq, g["seq"]) < 1e-5 and rel(pooled, g["pooled"]) < 1e-5
+    assert rel(OO.bert_latent_mu(sd, "encoder", pooled), g["mu"]) < 1e-5
+    keys = set(net.state_dict())
+    assert {"embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight",
+            "embeddings.LayerNorm.bias", "encoder.layer.1.attention.self.query.weight", "encoder.layer.0.attention.output.dense.bias",
+            "encoder.layer.0.attention.output.LayerNorm.weight", "encoder.layer.1.intermediate.dense.weight",
+            "encoder.layer.1.output.dense.weight", "encoder.layer.1.output.LayerNorm.bias", "pooler.dense.weight", "linear.weight"} <= keys
+    assert len(keys) == 5 + 16 * cfg["num_hidden_layers"] + 2 + 1
+    assert net.linear.weight.shape == (2 * cfg["latent_size"], cfg["hidden_size"])
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_bert_tokenizer_matches_reference(full, tmp_path):
+    """The product's BERT basic + WordPiece tokenizer against pieces / ids the reference's vendored BertTokenizer produced
+    (cased and lower-casing variants, accents, CJK, punctuation runs, an over-long word, a special token inside the text);
+    with the published vocabulary when the reference checkout is present, and always with the reduced one."""
+    from lib.model_zoo.optimus import optimus_bert_tokenizer
+    published = "/root/reference/lib/model_zoo/optimus_models/vocab/bert-base-cased-vocab.txt"
+    if full and not os.path.exists(published):
+        pytest.skip("published BERT vocabulary lives in the reference checkout")
+    vocab = published if full else reduced_bert_vocab(str(tmp_path / "vocab.txt"))
+    tk = _bert_meta()["tokenizer"]
+    tok = optimus_bert_tokenizer(vocab_file=vocab, do_lower_case=False, max_len=512)
+    assert [tok.cls_token_id, tok.sep_token_id, tok.pad_token_id, tok.unk_token_id] == tk["special"] and len(tok) == tk["len"]
+    assert tok.add_special_tokens_single_sentence([5, 6]) == tk["with_special"]
+    for c in tk["cases"]:
+        assert tok.tokenize(c["text"]) == c["pieces"], c["text"]
+        assert [tok._convert_token_to_id(p) for p in c["pieces"]] == c["ids"]
+    if full:
+        lc = optimus_bert_tokenizer(vocab_file=vocab, do_lower_case=True, max_len=512)
+        for c in tk["cases_lower"]:
+            assert lc.tokenize(c["text"]) == c["pieces"], c["text"]
+    assert tok.tokenize("   ") == [] and tok.tokenize("") == []
+    with pytest.raises(FileNotFoundError):
+        optimus_bert_tokenizer(vocab_file="/nonexistent/vocab.txt").tokenize("a")

@@ -191,6 +191,24 @@ __global__ void axpby_tail_kernel(const f16* x, const f16* y, f16* out, float a,
     if (i < n) out[i] = (f16)(a * (float)x[i] + b * (float)y[i]);
 }
 
+// out = f(x) element-wise, f = erf-GELU (op 0) or tanh (op 1): BERT's intermediate activation and pooler of the Optimus
+// encoder, kept out of the GEMM epilogue's activation switch (a one-off text encode, not worth code in every instance)
+__device__ __forceinline__ float unary_op(int op, float v) {
+    if (op == 0) return vd_gelu_erf(v);
+    return 1.0f - 2.0f / (1.0f + __expf(2.0f * v));
+}
+__global__ void unary_kernel(const f16* x, f16* out, int op, size_t n8, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        U4H8 xv, o;
+        xv.u = reinterpret_cast<const uint4*>(x)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)unary_op(op, (float)xv.e[j]);
+        reinterpret_cast<uint4*>(out)[i] = o.u;
+    }
+    if (blockIdx.x == 0 && n8 * 8 + threadIdx.x < n && threadIdx.x < 8)
+        out[n8 * 8 + threadIdx.x] = (f16)unary_op(op, (float)x[n8 * 8 + threadIdx.x]);
+}
+
 __global__ void embed_tokens_kernel(const int64_t* ids, const f16* tok, const f16* pos, f16* out, int B, int L, int C) {
     const int C8 = C / 8;
     const size_t n = (size_t)B * L * C8;
@@ -406,6 +424,13 @@ extern "C" int vd_axpby_f16(const void* x, const void* y, void* out, float a, fl
         hipLaunchKernelGGL(axpby_tail_kernel, dim3(1), dim3(8), 0, stream, (const f16*)x, (const f16*)y, (f16*)out, a,
                            b, n8 * 8, (size_t)n);
     return vd_check_launch("vd_axpby_f16");
+}
+
+extern "C" int vd_unary_f16(const void* x, void* out, int op, int64_t n, hipStream_t stream) {
+    VD_REQUIRE(x && out && n > 0 && (op == VD_UNARY_GELU_ERF || op == VD_UNARY_TANH), "vd_unary_f16: bad arguments");
+    const size_t n8 = (size_t)n / 8;
+    hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n8 > 0 ? n8 : 1)), dim3(256), 0, stream, (const f16*)x, (f16*)out, op, n8, (size_t)n);
+    return vd_check_launch("vd_unary_f16");
 }
 
 extern "C" int vd_embed_tokens_f16(const int64_t* ids, const void* tok_emb, const void* pos_emb, void* out, int B,

@@ -51,10 +51,10 @@ __device__ __forceinline__ float gn_shift(const f16* x0, int c0, const f16* x1, 
     return (float)*gn_src(x0, c0, x1, c1, row0, group * cg);
 }
 
-// shifts of the 8 consecutive channels starting at ch (a multiple of 8): with cg >= 4 they span at most two groups, so two
-// loads serve all 8
+// shifts of the 8 consecutive channels starting at ch (a multiple of 8): with cg >= 8 (or cg == 4) they span at most two
+// groups, so two loads serve all 8
 __device__ __forceinline__ void gn_shift8(float* kk, const f16* x0, int c0, const f16* x1, int c1, size_t row0, int ch, int cg) {
-    if (cg < 4) {
+    if (cg < 8 && cg != 4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) kk[i] = gn_shift(x0, c0, x1, c1, row0, (ch + i) / cg, cg);
         return;

@@ -10,12 +10,19 @@ LayerNorm, the tanh-GELU MLP in the GEMM epilogue, and the tied lm_head as one f
 Token sampling itself (softmax on the device, then torch.multinomial) consumes the default generator exactly like the
 reference does.
 
-Not built: the ENCODE side (BERT connector, text -> latent; text-variation / text-to-text flows).  Its names stay
-resolvable (`optimus_bert_connector`, `optimus_bert_tokenizer`), checkpoints load with strict=False, `encode` raises.
+ENCODE side -- `optimus_vae_next.encode(text)` (reference :729-744): WordPiece ids -> 12-layer BERT
+(`optimus_bert_connector`, reference optimus_models/optimus_bert.py:1348-1439) -> pooled [CLS] -> `linear` -> the mean half
+of (mu, logvar) is the text latent.  Same kernels: embedding gather, LayerNorm, fused q/k/v GEMM, vd_attention_f16 with the
+padded keys simply left out (the reference adds -10000 to their scores, which is exp(.) = 0 in its fp32 softmax), dense +
+residual in the GEMM epilogue, erf-GELU / tanh as vd_unary_f16.  Both tokenizers are re-implemented on the host from the
+published algorithms (byte-level BPE; BERT basic + WordPiece); the vocabulary files are the published ones, looked up at
+the paths the reference's config names.
 """
 import json
 import math
 import os
+import re
+import unicodedata
 
 import torch
 import torch.nn as nn
@@ -28,25 +35,315 @@ from .hip_layers import PackCache, _h
 symbol = "optimus"
 
 
-class _NotBuilt(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-
-    def _no(self, *a, **k):
-        raise NotImplementedError("%s: the Optimus ENCODE side (BERT, text -> latent) is not built in this package; "
-                                  "decode (latent -> text) is" % type(self).__name__)
-
-    encode = forward = tokenize = _no
+# ---- BERT tokenizer: basic (whitespace / punctuation / CJK) splitting + greedy longest-match WordPiece ----------------------
+def _is_space(ch):
+    return ch in " \t\n\r" or unicodedata.category(ch) == "Zs"
 
 
-@register("optimus_bert_connector")
-class optimus_bert_connector(_NotBuilt):
-    pass
+def _is_ctrl(ch):
+    return ch not in "\t\n\r" and unicodedata.category(ch).startswith("C")
+
+
+def _is_punct(ch):
+    cp = ord(ch)
+    ascii_punct = 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126   # all non-alphanumeric ASCII
+    return ascii_punct or unicodedata.category(ch).startswith("P")
+
+
+_CJK_RANGES = ((0x4E00, 0x9FFF), (0x3400, 0x4DBF), (0x20000, 0x2A6DF), (0x2A700, 0x2B73F), (0x2B740, 0x2B81F),
+               (0x2B820, 0x2CEAF), (0xF900, 0xFAFF), (0x2F800, 0x2FA1F))
+
+
+def _is_cjk(ch):
+    cp = ord(ch)
+    return any(lo <= cp <= hi for lo, hi in _CJK_RANGES)
 
 
 @register("optimus_bert_tokenizer")
-class optimus_bert_tokenizer(_NotBuilt):
-    pass
+class optimus_bert_tokenizer(nn.Module):
+    """BERT tokenizer with the surface `optimus_vae_next.encode` uses (reference optimus_models/tokenization_bert.py:101-457,
+    tokenization_utils.py:576-640): `tokenize`, `_convert_token_to_id`, `convert_tokens_to_ids`,
+    `add_special_tokens_single_sentence`, `encode`, the `*_token` / `*_token_id` attributes.  The algorithm is the
+    published one (Devlin et al., `tokenization.py`): drop control characters, map unicode spaces to ' ', isolate CJK
+    characters, split on whitespace, (lower-case + strip accents when do_lower_case), split every punctuation character
+    off, then per word the greedy longest-prefix match against the vocabulary with '##' continuation pieces; words over
+    100 characters or with an unmatched remainder become [UNK].  Special tokens inside the text are kept whole.
+    One deliberate difference: a whitespace-only string gives [] (the reference's added-token splitter emits one
+    special token picked from a `set`, i.e. depending on the process's hash seed)."""
+
+    def __init__(self, vocab_file=None, do_lower_case=True, do_basic_tokenize=True, never_split=None, unk_token="[UNK]",
+                 sep_token="[SEP]", pad_token="[PAD]", cls_token="[CLS]", mask_token="[MASK]", tokenize_chinese_chars=True,
+                 max_len=512, **kwargs):
+        super().__init__()
+        self.vocab = {}
+        if vocab_file is not None and os.path.exists(vocab_file):
+            with open(vocab_file, encoding="utf-8") as f:
+                for i, line in enumerate(f):
+                    self.vocab[line.rstrip("\n")] = i
+        self.vocab_file = vocab_file
+        self.ids_to_tokens = {i: t for t, i in self.vocab.items()}
+        self.do_lower_case, self.do_basic_tokenize = do_lower_case, do_basic_tokenize
+        self.never_split = list(never_split or [])
+        self.tokenize_chinese_chars = tokenize_chinese_chars
+        self.unk_token, self.sep_token, self.pad_token = unk_token, sep_token, pad_token
+        self.cls_token, self.mask_token = cls_token, mask_token
+        self.max_len = max_len
+        self.max_len_single_sentence = max_len - 2
+        self.max_input_chars_per_word = 100
+
+    def _need_vocab(self):
+        if not self.vocab:
+            raise FileNotFoundError("optimus_bert_tokenizer: vocabulary file %r not found (the published "
+                                    "bert-base-cased-vocab.txt; path is CWD-relative like in the reference)" % (self.vocab_file,))
+
+    @property
+    def all_special_tokens(self):
+        return [self.unk_token, self.sep_token, self.pad_token, self.cls_token, self.mask_token]
+
+    @property
+    def vocab_size(self):
+        return len(self.vocab)
+
+    def __len__(self):
+        return len(self.vocab)
+
+    cls_token_id = property(lambda self: self._convert_token_to_id(self.cls_token))
+    sep_token_id = property(lambda self: self._convert_token_to_id(self.sep_token))
+    pad_token_id = property(lambda self: self._convert_token_to_id(self.pad_token))
+    unk_token_id = property(lambda self: self._convert_token_to_id(self.unk_token))
+
+    # -- basic tokenisation of one piece of text that holds no special tokens
+    def _words(self, text):
+        cleaned = []
+        for ch in text:
+            if ord(ch) in (0, 0xFFFD) or _is_ctrl(ch):
+                continue
+            if _is_space(ch):
+                cleaned.append(" ")
+            elif self.tokenize_chinese_chars and _is_cjk(ch):
+                cleaned.append(" " + ch + " ")
+            else:
+                cleaned.append(ch)
+        words = []
+        for word in "".join(cleaned).split():
+            if self.do_lower_case and word not in self.never_split:
+                word = "".join(c for c in unicodedata.normalize("NFD", word.lower()) if unicodedata.category(c) != "Mn")
+            run = ""
+            for ch in word:                       # every punctuation character is a word of its own
+                if _is_punct(ch):
+                    if run:
+                        words.append(run)
+                    words.append(ch)
+                    run = ""
+                else:
+                    run += ch
+            if run:
+                words.append(run)
+        return words
+
+    def _wordpiece(self, word):
+        if len(word) > self.max_input_chars_per_word:
+            return [self.unk_token]
+        pieces, start = [], 0
+        while start < len(word):
+            end = len(word)
+            while end > start:
+                cand = ("##" if start else "") + word[start:end]
+                if cand in self.vocab:
+                    break
+                end -= 1
+            if end == start:                      # nothing matched: the whole word is unknown
+                return [self.unk_token]
+            pieces.append(cand)
+            start = end
+        return pieces
+
+    def tokenize(self, text):
+        self._need_vocab()
+        specials = sorted(set(self.all_special_tokens), key=len, reverse=True)
+        parts = re.split("(" + "|".join(re.escape(t) for t in specials) + ")", text)
+        out = []
+        for part in parts:
+            if part in specials:
+                out.append(part)
+                continue
+            part = part.strip()
+            if not part:
+                continue
+            words = self._words(part) if self.do_basic_tokenize else part.split()
+            for w in words:
+                out.extend(self._wordpiece(w))
+        return out
+
+    def _convert_token_to_id(self, token):
+        self._need_vocab()
+        return self.vocab.get(token, self.vocab.get(self.unk_token))
+
+    def _convert_id_to_token(self, index):
+        return self.ids_to_tokens.get(index, self.unk_token)
+
+    def convert_tokens_to_ids(self, tokens):
+        if isinstance(tokens, str):
+            return self._convert_token_to_id(tokens)
+        return [self._convert_token_to_id(t) for t in tokens]
+
+    def convert_tokens_to_string(self, tokens):
+        return " ".join(tokens).replace(" ##", "").strip()
+
+    def add_special_tokens_single_sentence(self, token_ids):
+        return [self.cls_token_id] + list(token_ids) + [self.sep_token_id]
+
+    def encode(self, text, add_special_tokens=False):
+        ids = self.convert_tokens_to_ids(self.tokenize(text))
+        return self.add_special_tokens_single_sentence(ids) if add_special_tokens else ids
+
+
+# ---- BERT encoder with the latent head ---------------------------------------------------------------------------------------
+class _BertEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        H = _cfg(c, "hidden_size")
+        self.word_embeddings = nn.Embedding(_cfg(c, "vocab_size"), H, padding_idx=0)
+        self.position_embeddings = nn.Embedding(_cfg(c, "max_position_embeddings"), H)
+        self.token_type_embeddings = nn.Embedding(_cfg(c, "type_vocab_size", 2), H)
+        self.LayerNorm = nn.LayerNorm(H, eps=_cfg(c, "layer_norm_eps", 1e-12))
+
+
+class _BertSelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        H = _cfg(c, "hidden_size")
+        self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+
+
+class _BertDenseLN(nn.Module):          # BertSelfOutput / BertOutput: dense -> LayerNorm(. + input)
+    def __init__(self, n_in, H, eps):
+        super().__init__()
+        self.dense = nn.Linear(n_in, H)
+        self.LayerNorm = nn.LayerNorm(H, eps=eps)
+
+
+class _BertAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = _BertSelfAttention(c)
+        self.output = _BertDenseLN(_cfg(c, "hidden_size"), _cfg(c, "hidden_size"), _cfg(c, "layer_norm_eps", 1e-12))
+
+
+class _BertIntermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(_cfg(c, "hidden_size"), _cfg(c, "intermediate_size"))
+
+
+class _BertLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = _BertAttention(c)
+        self.intermediate = _BertIntermediate(c)
+        self.output = _BertDenseLN(_cfg(c, "intermediate_size"), _cfg(c, "hidden_size"), _cfg(c, "layer_norm_eps", 1e-12))
+
+
+class _BertEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([_BertLayer(c) for _ in range(_cfg(c, "num_hidden_layers"))])
+
+
+class _BertPooler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(_cfg(c, "hidden_size"), _cfg(c, "hidden_size"))
+
+
+@register("optimus_bert_connector")
+class optimus_bert_connector(nn.Module, PackCache):
+    """BertForLatentConnector (reference optimus_models/optimus_bert.py:1348-1439): BERT + `linear` [2*latent, hidden] (no
+    bias) that maps the pooled output to (mu, logvar).  `forward(input_ids, attention_mask)` returns
+    `(sequence_output [B, L, H], pooled_output [B, H])` as fp16 device tensors.  Masked (padding) keys are left out of the
+    attention -- every query row, padded ones included, still attends over the real tokens exactly as in the reference --
+    so samples run one at a time with their own key count.  Only the hidden_act = "gelu" (erf) configuration of the VD
+    checkpoint is built."""
+
+    def __init__(self, config, latent_size):
+        super().__init__()
+        assert _cfg(config, "hidden_act", "gelu") == "gelu", "optimus_bert_connector: only hidden_act='gelu' is built"
+        self.config = config
+        self.embeddings = _BertEmbeddings(config)
+        self.encoder = _BertEncoder(config)
+        self.pooler = _BertPooler(config)
+        self.linear = nn.Linear(_cfg(config, "hidden_size"), 2 * latent_size, bias=False)
+        self.n_head = _cfg(config, "num_attention_heads")
+        self.hidden = _cfg(config, "hidden_size")
+        std = _cfg(config, "initializer_range", 0.02)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                m.weight.data.normal_(mean=0.0, std=std)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+
+    def _w(self):
+        params = list(self.parameters())
+
+        def build():
+            e = self.embeddings
+            layers = []
+            for l in self.encoder.layer:
+                a = l.attention
+                layers.append(dict(
+                    qkv=(_h(torch.cat([a.self.query.weight, a.self.key.weight, a.self.value.weight], 0)),
+                         _h(torch.cat([a.self.query.bias, a.self.key.bias, a.self.value.bias], 0))),
+                    ao=(_h(a.output.dense.weight), _h(a.output.dense.bias)),
+                    aln=(_h(a.output.LayerNorm.weight), _h(a.output.LayerNorm.bias), a.output.LayerNorm.eps),
+                    fc=(_h(l.intermediate.dense.weight), _h(l.intermediate.dense.bias)),
+                    out=(_h(l.output.dense.weight), _h(l.output.dense.bias)),
+                    oln=(_h(l.output.LayerNorm.weight), _h(l.output.LayerNorm.bias), l.output.LayerNorm.eps)))
+            return dict(word=_h(e.word_embeddings.weight), pos=_h(e.position_embeddings.weight),
+                        type=_h(e.token_type_embeddings.weight), eln=(_h(e.LayerNorm.weight), _h(e.LayerNorm.bias), e.LayerNorm.eps),
+                        layers=layers, pool=(_h(self.pooler.dense.weight), _h(self.pooler.dense.bias)), lin=_h(self.linear.weight))
+        return self._packed("bert", tuple(params), build)
+
+    def _encode_one(self, w, ids, keep, type_ids, pos_ids):
+        """ids [L] long; keep [L] bool (attended keys); -> hidden states [L, H] of ALL L rows."""
+        L, H, dev = ids.shape[0], self.hidden, ids.device
+        order = torch.cat([keep.nonzero().view(-1), (~keep).nonzero().view(-1)])   # attended rows first (row-wise ops commute)
+        nk = int(keep.sum())
+        if nk == 0:
+            raise ValueError("optimus_bert_connector: a sample with no attended token")
+        ids, type_ids, pos_ids = ids[order], type_ids[order], pos_ids[order]
+        zero = torch.zeros((L, H), dtype=torch.float16, device=dev)
+        x = ops.embed_tokens(ids.view(1, L), w["word"], w["pos"][pos_ids].contiguous()).view(L, H)
+        x = ops.axpby(x, ops.embed_tokens(type_ids.view(1, L), w["type"], zero).view(L, H), 1.0, 1.0)
+        x = ops.layernorm(x, w["eln"][0], w["eln"][1], w["eln"][2])
+        for lw in w["layers"]:
+            qkv = ops.linear(x, lw["qkv"][0], lw["qkv"][1]).view(1, L, 3 * H)
+            a = ops.attention(qkv[..., :H], qkv[:, :nk, H:2 * H], qkv[:, :nk, 2 * H:], self.n_head, scale=(H // self.n_head) ** -0.5)
+            x = ops.layernorm(ops.linear(a.view(L, H), lw["ao"][0], lw["ao"][1], res=x), lw["aln"][0], lw["aln"][1], lw["aln"][2])
+            f = ops.unary(ops.linear(x, lw["fc"][0], lw["fc"][1]), ops.UNARY_GELU_ERF)
+            x = ops.layernorm(ops.linear(f, lw["out"][0], lw["out"][1], res=x), lw["oln"][0], lw["oln"][1], lw["oln"][2])
+        out = torch.empty_like(x)
+        out[order] = x
+        return out
+
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None):
+        assert head_mask is None, "optimus_bert_connector: head_mask is not supported"
+        w = self._w()
+        B, L = input_ids.shape
+        dev = self.linear.weight.device
+        input_ids = input_ids.to(dev)
+        keep = torch.ones((B, L), dtype=torch.bool, device=dev) if attention_mask is None else (attention_mask.to(dev) > 0.5)
+        type_ids = torch.zeros_like(input_ids) if token_type_ids is None else token_type_ids.to(dev)
+        pos_ids = torch.arange(L, device=dev).expand(B, L) if position_ids is None else position_ids.to(dev).expand(B, L)
+        seq = torch.stack([self._encode_one(w, input_ids[b], keep[b], type_ids[b], pos_ids[b]) for b in range(B)])
+        pooled = ops.unary(ops.linear(seq[:, 0].contiguous(), w["pool"][0], w["pool"][1]), ops.UNARY_TANH)
+        return seq, pooled
+
+    @torch.no_grad()
+    def latent_stats(self, pooled):
+        """(mu, logvar) = chunk(linear(pooled), 2)  (reference optimus.py:742)."""
+        ml = ops.linear(pooled.contiguous(), self._w()["lin"])
+        return ml.chunk(2, -1)
 
 
 # ---- GPT-2 byte-level BPE tokenizer (host-side text processing) ---------------------------------------------------------
@@ -414,8 +711,23 @@ class optimus_vae_next(nn.Module):
     def get_device(self):
         return self.decoder.transformer.wte.weight.device
 
+    @torch.no_grad()
     def encode(self, text, max_length=77):
-        raise NotImplementedError("optimus_vae_next.encode: the BERT encoder (text -> latent) is not built in this package")
+        """sentences -> text latent z_mu [B, nz] (reference optimus.py:729-744): lower-case, WordPiece, truncate to
+        max_length pieces, [CLS] .. [SEP], right-pad with 0, BERT with mask = (id > 0), pooled -> linear -> mean half."""
+        tok = self.tokenizer_encoder
+        rows = []
+        for sentence in text:
+            pieces = tok.tokenize(sentence.lower())[:max_length]
+            rows.append(tok.add_special_tokens_single_sentence([tok._convert_token_to_id(p) for p in pieces]))
+        L = max(len(r) for r in rows)
+        ids = torch.zeros((len(rows), L), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+        ids = ids.to(self.encoder.linear.weight.device)
+        pooled = self.encoder(ids, attention_mask=(ids > 0).float())[1]
+        z_mu, _ = self.encoder.latent_stats(pooled)
+        return z_mu
 
     @torch.no_grad()
     def decode(self, z, temperature=1.0):

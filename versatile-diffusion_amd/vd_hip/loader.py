@@ -58,6 +58,7 @@ PROTOTYPES = {
     "vd_im2col_small_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _F, _F, _P]),
     "vd_diag_gaussian_sample_f16": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "vd_axpby_f16": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "vd_unary_f16": (_I, [_P, _P, _I, _L, _P]),
     "vd_embed_tokens_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "vd_clip_vision_embed_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vd_patchify_f16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -405,6 +405,18 @@ def axpby(x, y, a, b, out=None):
     return out
 
 
+UNARY_GELU_ERF, UNARY_TANH = 0, 1
+
+
+def unary(x, op, out=None):
+    """out = erf-GELU(x) / tanh(x), element-wise (in place when out is x)."""
+    _req(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().vd_unary_f16(_ptr(x), _ptr(out), int(op), x.numel(), _stream()))
+    return out
+
+
 def embed_tokens(ids, tok_emb, pos_emb):
     _req(ids, "ids", torch.int64); _req(tok_emb, "tok_emb"); _req(pos_emb, "pos_emb")
     B, L = ids.shape
@@ -556,5 +568,5 @@ def _guarded(fn):
 for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
-              "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
+              "unary", "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
     globals()[_name] = _guarded(globals()[_name])
