@@ -55,9 +55,9 @@ typedef struct ihipStream_t* hipStream_t;
  *    LN(a)[m][k] = (a[m][k] - mean_m) * rstd_m * gamma[k] + beta[k]
  *    sum_k LN(a)[m][k] W[n][k] = rstd_m * ( sum_k a[m][k] W'[n][k] - mean_m * colsum[n] ) + bias'[n]
  * with W' = gamma (*) W (passed as `w`), colsum[n] = sum_k W'[n][k] (fp32) and bias' = beta W^T + bias (passed as `bias`),
- * all prepared once per layer by the host; mean / rstd come from the A tiles as they pass through LDS, so the
- * nn.LayerNorm in front of a projection (lib/model_zoo/attention.py:214-218) costs no pass over memory.
- * Plain (non-conv, single-source) A only, no split-K.
+ * all prepared once per layer by the host; (mean_m, rstd_m) are read from `ln_stats` (vd_row_stats_f16: one read of A,
+ * 8 bytes per row written), so the nn.LayerNorm in front of a projection (lib/model_zoo/attention.py:214-218) costs half
+ * a pass over memory instead of a read + write pass.  Plain (non-conv, single-source) A only, no split-K.
  * A[m][k] is gathered on the fly: m -> (b, oy, ox) over Hout x Wout, k -> (ky, kx, c) with c running
  * over the channels of a0 (c0) then a1 (c1) -- i.e. torch.cat([a0, a1], dim=1) is never materialised --
  * at input pixel ((oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups) (ups=1: nearest 2x upsample
@@ -82,12 +82,13 @@ typedef struct VdGemmDesc {
     int32_t split_k;     /* 0 = heuristic                                                        */
     int64_t stride_a, stride_w, stride_out, stride_res;
     const float* colsum; /* VD_EPI_LNFOLD: fp32 [N] row sums of w                                */
-    float ln_eps;        /* VD_EPI_LNFOLD: epsilon of the folded LayerNorm                       */
+    float ln_eps;        /* unused by the kernel (the epsilon is applied by vd_row_stats_f16); kept for layout */
     int32_t reserved;
     int32_t* sync;       /* optional split-K arrival counters: VD_GEMM_SYNC_INTS ints, ZERO before their first use and
                           * private to the stream (launches on one stream are ordered; the kernel leaves them zero).  With
                           * them the last-arriving block of each output tile sums the tile's fp32 slabs (in split order:
                           * results stay run-to-run identical) and runs the fused epilogue itself -- no reduce launch.   */
+    const float* ln_stats; /* VD_EPI_LNFOLD: fp32 [batch*M][2] = (mean, rstd) of every A row (vd_row_stats_f16)      */
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -134,6 +135,9 @@ int vd_groupnorm0d_silu_f16(const void* x0, int c0, const void* x1, int c1, cons
  * (lib/model_zoo/attention.py:205-207) and the HF CLIP layer norms. */
 int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                      hipStream_t stream);
+/* (mean, rstd = 1 / sqrt(var + eps)) of every row of x [rows][ldx >= C] (fp16, biased variance over the C columns,
+ * two-pass in registers) -> stats fp32 [rows][2]: the statistics half of nn.LayerNorm for VD_EPI_LNFOLD. */
+int vd_row_stats_f16(const void* x, float* stats, int64_t rows, int C, int64_t ldx, float eps, hipStream_t stream);
 
 /* Fused softmax(Q K^T * scale) V, online softmax, no score tensor in HBM.
  * q [B][Nq][ldq], k/v [B][Nk][ldk/ldv], out [B][Nq][ldo]; head h occupies columns h*D..h*D+D-1.

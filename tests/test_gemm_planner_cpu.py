@@ -65,7 +65,7 @@ def test_layernorm_fold_uses_fold_instances():
     for (M, N, K, act) in ((32768, 960, 320, 0), (32768, 2560, 320, 1), (512, 3840, 1280, 0), (2048, 1280, 1280, 0), (8, 1280, 320, 0)):
         d = VdGemmDesc()
         d.M, d.N, d.K, d.act = M, N, K, act
-        d.a0 = d.w = d.out = d.colsum = 16
+        d.a0 = d.w = d.out = d.colsum = d.ln_stats = 16
         d.flags = 32                                          # VD_EPI_LNFOLD
         d.ln_eps = 1e-5
         cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)

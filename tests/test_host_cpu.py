@@ -35,10 +35,11 @@ def test_capi_exports_every_declared_symbol():
 
 def test_gemm_desc_struct_matches_header():
     from vd_hip.loader import VdGemmDesc
-    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8
+    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8
     assert VdGemmDesc.stride_a.offset == 8 * 8 + 24 * 4
     assert VdGemmDesc.colsum.offset == 8 * 8 + 24 * 4 + 4 * 8   # LayerNorm-fold fields (ABI 2)
-    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 8   # split-K arrival counters (ABI 2)
+    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 16   # split-K arrival counters (ABI 2)
+    assert VdGemmDesc.ln_stats.offset == ctypes.sizeof(VdGemmDesc) - 8   # LayerNorm-fold row statistics (ABI 2)
 
 
 def test_model_cfg_bank_resolves_four_flow():

@@ -190,6 +190,19 @@ def test_gemm_layernorm_fold_geglu(ops, dev, M, C):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("rows,C,ld", [(1000, 320, 320), (4099, 640, 640), (77, 1280, 1280), (300, 768, 800), (33, 2048, 2048), (5, 64, 64)])
+def test_row_stats(ops, dev, rows, C, ld):
+    """vd_row_stats_f16 (statistics of the folded LayerNorm) vs torch fp32, incl. a padded leading dimension, rows that
+    do not fill a block, and a large common offset (two-pass: no cancellation)."""
+    x = rnd((rows, ld), dev, 1.5, 90) + 6.0
+    st = ops.row_stats(x, C, rows, 1e-5, ldx=ld)
+    xf = x[:, :C].float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + 1e-5).rsqrt()
+    assert st.shape == (rows, 2) and st.dtype == torch.float32
+    assert torch.allclose(st[:, 0], mean, rtol=1e-5, atol=1e-5) and torch.allclose(st[:, 1], rstd, rtol=1e-4, atol=0)
+
+
 def test_gemm_every_tile_configuration(ops, dev):
     """Every instantiation of the GEMM template (vd_gemm_set_override) on a conv with concat + row vector, a plain GEMM
     with ragged M / N / K and bias + residual, a split-K problem, a LayerNorm-folded projection and a GEGLU projection

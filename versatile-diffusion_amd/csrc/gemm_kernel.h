@@ -231,6 +231,9 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int BM, int BN, int NT, int STAGES, int KB>
+constexpr int gemm_lds_bytes();   // stages / epilogue tile (defined with the launcher below)
+
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
 __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     // wave tiles of 8+ MFMA tiles at two waves per SIMD (256 registers each) cannot hold two fragment sets next to the
@@ -286,6 +289,23 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int z = blockIdx.z;
+
+    // LayerNorm fold: the block's BN entries of colsum wait in LDS behind the stages / the epilogue tile, so the epilogue's
+    // register phase reads them with ds_read instead of one more global round trip per column group
+    if constexpr (LNF) {
+        float* ln_cs = reinterpret_cast<float*>(smem + gemm_lds_bytes<BM, BN, NT, STAGES, KB>());
+        for (int c = tid * 4; c < BN; c += NT * 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + c + 4 <= d.N) v = *reinterpret_cast<const float4*>(d.colsum + n0 + c);
+            else {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + c + q < d.N) t[q] = d.colsum[n0 + c + q];
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            *reinterpret_cast<float4*>(ln_cs + c) = v;
+        }
+    }
 
     // ---- operands are read through buffer descriptors: one SGPR base + per-lane 32-bit byte offset + a scalar
     // K offset per tile.  Out-of-image taps, rows >= M / N and the ragged K tail simply use an out-of-range
@@ -424,35 +444,19 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         }
     };
 
-    // LayerNorm fold (VD_EPI_LNFOLD): row statistics of A are accumulated from the LDS-resident A tiles -- each thread
-    // re-reads the 16 bytes per pass it DMA'd itself -- so the consumer GEMM needs no separate LayerNorm pass at all.
-    // LNF is a compile-time property of the instantiation: as a run-time flag the (never taken) branch in the K loop and
-    // the statistics registers cost every OTHER launch 1-2 % (0.2 ms per UNet forward, measured with the fold compiled out)
+    // LayerNorm fold (VD_EPI_LNFOLD): the epilogue applies rstd * acc - rstd * mean * colsum with the row statistics of A
+    // read from d.ln_stats (vd_row_stats_f16).  Round 2 first accumulated them inside the K loop from the LDS-resident A
+    // tiles (no extra pass over A at all), but every column block of a row panel repeats that work and the loop of the
+    // short-K projections has no slack for it: +24 us on the 57 us q/k/v projection of the 64x64 level, +35 us on its
+    // GEGLU projection -- as much as the LayerNorm launches the fold removes.  LNF stays a compile-time property of the
+    // instantiation so that launches without it carry none of this.
     constexpr bool lnf = LNF;
-    float ln_s[A_PASSES], ln_q[A_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < A_PASSES; ++ps) ln_s[ps] = ln_q[ps] = 0.f;
-    auto ln_accumulate = [&](const char* st) {
-#pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            union { uint4 u; f16x2 h2[4]; } t;
-            t.u = *reinterpret_cast<const uint4*>(st + ps * RPP * KROW_BYTES + tid * 16);
-            const f16x2 ones = {(f16)1.0f, (f16)1.0f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ln_s[ps] = __builtin_amdgcn_fdot2(t.h2[q], ones, ln_s[ps], false);
-                ln_q[ps] = __builtin_amdgcn_fdot2(t.h2[q], t.h2[q], ln_q[ps], false);
-            }
-        }
-    };
-
     // one iteration = one K tile.  MODE 0: steady state (issues tile i + D, leaves D - 1 tiles in flight at the wait),
     // MODE 1: drain (nothing left to issue), MODE 2: last tile (no successor to wait for).
     auto iteration = [&](auto mode_tag, int i, int cbuf, int nbuf, int ibuf) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char* st = smem + cbuf * STAGE_BYTES;
         if constexpr (MODE == 0) issue_begin(kt0 + i + D, ibuf);
-        if (lnf) ln_accumulate(st);
         if constexpr (FB == 1) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -549,8 +553,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
             }
             const char* st = smem + cbuf * STAGE_BYTES;
-            if (lnf) ln_accumulate(st);
-#pragma unroll
+    #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 f16x8 af[MI], bf[NI];
                 read_frags(st, ks, af, bf);
@@ -693,9 +696,13 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                         if (col + 4 <= d.N && (ld & 3) == 0) {
                             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
+                            // ragged edge, element by element.  volatile keeps this path apart from the 16-byte store above:
+                            // hipcc otherwise merges the two (one dwordx3 + a shared conditional dword store per group,
+                            // i.e. twice the store instructions and no full 16-byte writes; +4 us per split-K launch)
+                            volatile float* ov = o;
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                if (col + q < d.N) o[q] = v[q];
+                                if (col + q < d.N) ov[q] = v[q];
                         }
                     }
                 }
@@ -709,28 +716,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     const bool geglu = (d.act == VD_ACT_GEGLU);
     const int out_n0 = geglu ? tn * (BN / 2) : n0;
 
-    // LayerNorm fold: mean / rstd per row of the block into LDS behind the epilogue tile
-    float2* lnst = reinterpret_cast<float2*>(smem + EPI_BYTES);
-    if (lnf) {
-#pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            float s = ln_s[ps], q = ln_q[ps];
-#pragma unroll
-            for (int o = 1; o < SLOTS; o <<= 1) {
-                s += __shfl_xor(s, o, 64);
-                q += __shfl_xor(q, o, 64);
-            }
-            if (lslot == 0 && lrow + RPP * ps < BM) {
-                const float inv_k = 1.0f / (float)d.K;
-                const float mean = s * inv_k;
-                float var = q * inv_k - mean * mean;
-                if (var < 0.f) var = 0.f;
-                lnst[lrow + RPP * ps] = make_float2(mean, rsqrtf(var + d.ln_eps));
-            }
-        }
-        __syncthreads();
-    }
-    const float* colsum = d.colsum;
+    const float* ln_cs = reinterpret_cast<const float*>(smem + gemm_lds_bytes<BM, BN, NT, STAGES, KB>());   // block-local colsum
 
     // residual / row-vector segments of part 2 are requested NOW so their latency overlaps part 1 (the block is
     // short-lived on the K = 320..1280 projections: every serial memory round trip shows)
@@ -754,7 +740,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         if ((e.flags & VD_EPI_BIAS) && (e.flags & VD_EPI_BIAS_ALONG_M) && row < d.M) bm = (float)e.bias[row];
         float ln_rstd = 1.f, ln_nmr = 0.f;  // y = rstd * acc - (mean * rstd) * colsum[n] + bias'[n]
         if (lnf) {
-            const float2 st = lnst[lrow_t];
+            const float2 st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
             ln_rstd = st.y;
             ln_nmr = -st.x * st.y;
         }
@@ -777,8 +763,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     }
                     float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), cg = cv;
                     if (lnf) {
-                        cv = *reinterpret_cast<const float4*>(colsum + pn);
-                        cg = *reinterpret_cast<const float4*>(colsum + pn + 32);
+                        cv = *reinterpret_cast<const float4*>(ln_cs + (pn - n0));
+                        cg = *reinterpret_cast<const float4*>(ln_cs + (pn - n0) + 32);
                     }
                     const float cva[4] = {cv.x, cv.y, cv.z, cv.w}, cga[4] = {cg.x, cg.y, cg.z, cg.w};
 #pragma unroll
@@ -810,18 +796,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                                 if (col + q < d.N) bq[q] = (float)e.bias[col + q];
                         }
                     }
-                    if (lnf) {
-                        if (col + 4 <= d.N) {
-                            const float4 c4 = *reinterpret_cast<const float4*>(colsum + col);
-                            bq[0] = fmaf(ln_nmr, c4.x, bq[0]);
-                            bq[1] = fmaf(ln_nmr, c4.y, bq[1]);
-                            bq[2] = fmaf(ln_nmr, c4.z, bq[2]);
-                            bq[3] = fmaf(ln_nmr, c4.w, bq[3]);
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (col + q < d.N) bq[q] = fmaf(ln_nmr, colsum[col + q], bq[q]);
-                        }
+                    if (lnf) {   // columns past N hold zeros
+                        const float4 c4 = *reinterpret_cast<const float4*>(ln_cs + lc);
+                        bq[0] = fmaf(ln_nmr, c4.x, bq[0]);
+                        bq[1] = fmaf(ln_nmr, c4.y, bq[1]);
+                        bq[2] = fmaf(ln_nmr, c4.z, bq[2]);
+                        bq[3] = fmaf(ln_nmr, c4.w, bq[3]);
                     }
                     U2H4 o;
                     if (e.act == VD_ACT_NONE) {
@@ -855,7 +835,7 @@ constexpr int gemm_lds_bytes() {
 
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
-    constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>();
+    constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>() + (LNF ? BN * 4 : 0);   // + the block's colsum entries
     static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
     // the dynamic-LDS attribute is per device: one bit per device ordinal, set idempotently (safe under concurrent callers)
     static std::atomic<unsigned long long> done{0};

@@ -499,6 +499,58 @@ extern "C" int vd_groupnorm0d_silu_f16(const void* x0, int c0, const void* x1, i
     return vd_check_launch("vd_groupnorm0d_silu_f16");
 }
 
+namespace {
+// Row statistics for the LayerNorm fold of vd_gemm_f16: 16 lanes per row (4 rows per wave, 16 per block), every 16-byte
+// load of a row issued before the first is consumed, mean first, then the centred sum of squares from registers.
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_kernel(const f16* x, float* stats, long rows, int C, long ldx, float eps) {
+    const int sub = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long r = row < rows ? row : rows - 1;
+    const int C8 = C >> 3;
+    const f16* xr = x + r * ldx;
+    U4H8 t[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int cc = sub + 16 * j;
+        t[j].u = cc < C8 ? *reinterpret_cast<const uint4*>(xr + cc * 8) : make_uint4(0, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (float)t[j].e[i];      // lanes past C hold zeros
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (sub + 16 * j < C8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dlt = (float)t[j].e[i] - mean;
+                q += dlt * dlt;
+            }
+        }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (sub == 0 && row < rows) reinterpret_cast<float2*>(stats)[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
+}
+}  // namespace
+
+extern "C" int vd_row_stats_f16(const void* x, float* stats, int64_t rows, int C, int64_t ldx, float eps, hipStream_t stream) {
+    VD_REQUIRE(x && stats && rows > 0 && C > 0 && C % 8 == 0 && C <= 2048 && ldx >= C && ldx % 8 == 0,
+               "vd_row_stats_f16: bad arguments (rows=%ld C=%d ldx=%ld; C %% 8 == 0, C <= 2048)", (long)rows, C, (long)ldx);
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    const int nch = (C / 8 + 15) / 16;
+    if (nch <= 3) hipLaunchKernelGGL(row_stats_kernel<3>, grid, block, 0, stream, (const f16*)x, stats, (long)rows, C, (long)ldx, eps);
+    else if (nch <= 5) hipLaunchKernelGGL(row_stats_kernel<5>, grid, block, 0, stream, (const f16*)x, stats, (long)rows, C, (long)ldx, eps);
+    else if (nch <= 10) hipLaunchKernelGGL(row_stats_kernel<10>, grid, block, 0, stream, (const f16*)x, stats, (long)rows, C, (long)ldx, eps);
+    else hipLaunchKernelGGL(row_stats_kernel<16>, grid, block, 0, stream, (const f16*)x, stats, (long)rows, C, (long)ldx, eps);
+    return vd_check_launch("vd_row_stats_f16");
+}
+
 extern "C" int vd_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,
                                 float eps, hipStream_t stream) {
     VD_REQUIRE(x && gamma && beta && y, "vd_layernorm_f16: null pointer");

@@ -1,6 +1,6 @@
 """Optimus text VAE behind the reference's registry names (lib/model_zoo/optimus.py:16-763 there).
 
-Built here: the DECODE side -- `optimus_vae_next.decode(z)` (reference :748-763): the 768-d text latent the 0-D diffuser
+DECODE side -- `optimus_vae_next.decode(z)` (reference :748-763): the 768-d text latent the 0-D diffuser
 produces conditions a 12-layer GPT-2 (`optimus_gpt2_connector`, reference optimus_models/optimus_gpt2.py:813-1100) in two
 ways, as an embedding added to every token (`linear_emb`) and as one extra key/value "memory" slot per layer (`linear`),
 and tokens are sampled one at a time (multinomial, temperature 1, <= 30 tokens).  The network runs on the HIP kernel
@@ -689,7 +689,9 @@ def top_k_top_p_filtering(probs, top_k=0, top_p=1.0):
 @register("optimus_vae_next")
 class optimus_vae_next(nn.Module):
     """optimus_vae / optimus_vae_next (reference optimus.py:17-60, 724-763): holds encoder, decoder and the two
-    tokenizers; `decode(z)` turns text latents into sentences."""
+    tokenizers; `encode(text)` turns sentences into text latents (the posterior mean), `decode(z)` text latents into
+    sentences.  The training-side methods of the reference class (loss, importance-weighted bounds, MI / AU statistics)
+    are not part of the sampling path and are not built."""
 
     def __init__(self, encoder, decoder, tokenizer_encoder, tokenizer_decoder, args):
         super().__init__()

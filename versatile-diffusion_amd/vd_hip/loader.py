@@ -26,7 +26,7 @@ class VdGemmDesc(ctypes.Structure):
         ("stride_a", ctypes.c_int64), ("stride_w", ctypes.c_int64), ("stride_out", ctypes.c_int64),
         ("stride_res", ctypes.c_int64),
         ("colsum", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
-        ("sync", ctypes.c_void_p),
+        ("sync", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p),
     ]
 
 
@@ -46,6 +46,7 @@ PROTOTYPES = {
     "vd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "vd_row_stats_f16": (_I, [_P, _P, _L, _I, _L, _F, _P]),
     "vd_attention_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P]),
     "vd_softmax_rows_f32_f16": (_I, [_P, _P, _L, _I, _P]),
     "vd_softmax_rows_f32_f32": (_I, [_P, _P, _L, _I, _F, _P]),

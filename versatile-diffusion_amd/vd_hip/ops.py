@@ -126,14 +126,24 @@ def drop_workspaces(stream_id):
         del _ws_cache[k]
 
 
+def row_stats(x, C, rows, eps, ldx=None):
+    """(mean, rstd) per row of x viewed as [rows][ldx >= C] -> fp32 [rows, 2] (the statistics half of a LayerNorm)."""
+    _req(x, "x")
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with _Timed("row_stats_kernel", 0.0, rows * C * 2.0 + rows * 8.0):
+        _check(lib().vd_row_stats_f16(_ptr(x), _ptr(stats), int(rows), int(C), int(ldx or C), float(eps), _stream()))
+    return stats
+
+
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
-    colsum (fp32 [N]) + ln_eps: the rows of A are layer-normalised on the fly (VD_EPI_LNFOLD); w / bias are then the
-    folded gamma (*) W and beta W^T + bias (hip_layers.fold_layernorm).
+    colsum (fp32 [N]) + ln_eps: the rows of A are layer-normalised on the fly (VD_EPI_LNFOLD: row statistics from
+    vd_row_stats_f16, applied in the GEMM epilogue); w / bias are then the folded gamma (*) W and beta W^T + bias
+    (hip_layers.fold_layernorm).
     fixup=True: split-K slabs are summed by the last-arriving block of each tile (VdGemmDesc.sync) instead of the reduce
     kernel; default from VD_GEMM_FIXUP (off: the in-kernel tail measured 0.2 ms per UNet forward slower than the launch).
     """
@@ -177,9 +187,13 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         flags |= EPI_RESIDUAL
     if out_f32:
         flags |= EPI_OUT_F32
+    ln_stats = None
     if colsum is not None:
+        if conv is not None or a1 is not None or max(batch, 1) != 1:
+            raise VdHipError("gemm: the LayerNorm fold takes a plain single-source, unbatched A")
         flags |= EPI_LNFOLD
-        d.colsum, d.ln_eps = colsum.data_ptr(), float(ln_eps)
+        ln_stats = row_stats(a0, int(K), int(M), float(ln_eps), ldx=int(lda0) if lda0 else int(K))
+        d.colsum, d.ln_eps, d.ln_stats = colsum.data_ptr(), float(ln_eps), ln_stats.data_ptr()
     d.flags, d.act, d.alpha = flags, int(act), float(alpha)
     d.batch, d.split_k = int(batch), int(split_k)
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = [int(s) for s in strides]
@@ -565,7 +579,7 @@ def _guarded(fn):
     return wrapper
 
 
-for _name in ("gemm", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
+for _name in ("gemm", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
               "unary", "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
