@@ -16,6 +16,12 @@
  *   - statistics (GroupNorm, LayerNorm, softmax) and MFMA accumulation are fp32
  *   - return value: 0 on success, negative VD_ERR_* otherwise; vd_last_error() returns the
  *     thread-local message of the last failure
+ *   - threads: entry points may be called concurrently from several host threads (one stream per
+ *     thread).  Process-wide state is limited to the optional tuned launch table (vd_gemm_tune_*,
+ *     mutex-protected), the developer tile override (atomic), per-device kernel attributes
+ *     (atomic bit mask, idempotent) and development switches read once from the environment
+ *     (VD_GEMM_VARIANT / VD_GEMM_NT / VD_GEMM_TILE: function-local statics, initialised under the
+ *     C++11 guarantee).  Scratch (workspaces, split-K counters) is caller-owned, one set per stream.
  */
 #ifndef VD_HIP_H
 #define VD_HIP_H
@@ -27,9 +33,7 @@
 extern "C" {
 #endif
 
-#ifndef __HIP_PLATFORM_AMD__
-typedef struct ihipStream_t* hipStream_t;
-#endif
+typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
 #define VD_HIP_ABI_VERSION 2
 #define VD_MAX_SPLIT_K 32
