@@ -17,18 +17,20 @@
 // Structure of a block (BM x BN output tile, NT/64 waves, wave tile WM x WN = MI x NI MFMA tiles of 32x32):
 //   * K is walked in KB-deep tiles through a ring of STAGES LDS buffers.  Tiles travel global -> LDS by LDS-DMA
 //     (buffer_load ... lds: no VGPR round trip, no ds_write); the XOR swizzle of the LDS image is applied on the source
-//     side.  A tile is issued STAGES-1 tiles ahead, in PIECES (one 1-KiB wave instruction each) that are spread between
-//     the MFMAs of the first k-steps of an iteration: issued in one burst they cost the wave 60-180 issue cycles apiece
-//     with the matrix pipe idle.
-//   * Operand fragments are double-buffered in registers and the pipeline runs ACROSS the per-tile barrier: the
-//     fragments of k-step 0 of tile i+1 are requested right after the barrier and the MFMAs of the last k-step of tile i
-//     are issued behind them, so the ds_read latency after a barrier is covered by matrix work.
+//     side.  Default main loop ("burst"): wait for tile i, barrier, issue ALL DMA instructions of tile i + STAGES - 1,
+//     then the fragment reads and MFMAs of tile i.  -DVD_GEMM_PIPELINED builds the software-pipelined alternative (DMA
+//     issued in 1-KiB pieces between MFMA groups, operand fragments double-buffered across the per-tile barrier): faster
+//     in a warm sweep, 4 % slower inside the UNet forward where weights stream cold from HBM.
 //   * v_mfma_f32_32x32x16_f16, fp32 accumulation, operands swapped (MFMA A operand = W rows, B operand = activation
 //     rows) so a lane owns ONE output row and 4 consecutive columns per register group: bias / LayerNorm fold /
 //     activation / GEGLU gating / alpha run in registers, the tile is staged through LDS and leaves as 16-byte row
 //     segments with the per-batch row vector and the residual added on the way out.
-//   * LDS bandwidth is the resource to economise (reads: (MI+NI)/(MI*NI) KiB per MFMA; DMA writes: (BM+BN)*KB*2 bytes
-//     per tile): hence the one-wave-per-SIMD instances with 64x160 / 64x128 wave tiles in gemm_big.hip.
+//   * Larger wave tiles cut LDS traffic per MFMA (reads: (MI+NI)/(MI*NI) KiB per MFMA; DMA writes: (BM+BN)*KB*2 bytes per
+//     tile): the one-wave-per-SIMD and 64x128 / 64x160-per-wave instances of gemm_big.hip exist for that and for the
+//     experiments DESIGN.md reports; the UNet's shapes do not reward them.
+//   * LayerNorm fold (LNF instances): (mean, rstd) per row from d.ln_stats, the block's colsum slice from LDS.
+//   * split-K: fp32 slabs + splitk_reduce_kernel (gemm.hip); optional in-kernel reduction by the last-arriving block
+//     (d.sync, agent-scope atomics) -- correct, slower, off by default.
 #pragma once
 #include "vd_common.h"
 #include "../../include/vd_hip.h"
