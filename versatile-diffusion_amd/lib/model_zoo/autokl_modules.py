@@ -5,7 +5,6 @@ Upsample :42-57, Downsample :60-79, ResnetBlock :82-141, AttnBlock :150-202, Enc
 Convs are implicit MFMA GEMMs with the nearest-2x upsample / the asymmetric (0,1,0,1) stride-2 padding folded into
 the gather; GroupNorm(eps 1e-6)+swish is one pass; the single-head mid attention (C=512, N=HW) runs as batched
 GEMMs with fp32 logits (fp16 would overflow there) and a row-softmax kernel."""
-import torch
 import torch.nn as nn
 
 from vd_hip import ops

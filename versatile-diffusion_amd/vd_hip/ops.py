@@ -6,7 +6,6 @@ No arithmetic is done in torch here.
 """
 import ctypes
 import functools
-import math
 import os
 
 import torch
