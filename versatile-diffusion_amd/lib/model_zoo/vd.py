@@ -65,9 +65,13 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
             kv = None
             if cache is not None:
                 kv = cache.get(id(module))
+                stale = cache.get("_stale")
                 if kv is None:
                     kv = module[0].project_context(c)
                     cache[id(module)] = kv
+                elif stale and id(module) in stale:   # buffer a captured graph reads: new context, same storage
+                    kv.copy_(module[0].project_context(c))
+                    stale.discard(id(module))
             # h_out = sum_i r_i * ST_i(h) = sum_i r_i * proj_i + h   (sum r_i = 1): chained through the epilogue
             out = module(h, None, c, kv=kv, alpha=1.0 if single else float(r), res=out)
         return out
