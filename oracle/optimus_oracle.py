@@ -102,3 +102,19 @@ def bert_forward(sd, p, input_ids, attention_mask, n_head, n_layer, eps=1e-12):
 def bert_latent_mu(sd, p, pooled):
     """optimus.py:742-744: z_mu = first half of encoder.linear(pooled)"""
     return (pooled @ sd[p + ".linear.weight"].t()).chunk(2, -1)[0]
+
+
+def top_k_top_p_filtering(logits, top_k=0, top_p=0.0):
+    """optimus.py:690-721: logits of one step -> logits with the filtered tokens at -inf (top-k first, then the nucleus on
+    what is left; the first token above the threshold is kept)."""
+    logits = logits.clone()
+    top_k = min(top_k, logits.size(-1))
+    if top_k > 0:
+        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = -float("inf")
+    if top_p > 0.0:
+        sl, si = torch.sort(logits, descending=True)
+        rm = torch.cumsum(F.softmax(sl, dim=-1), dim=-1) > top_p
+        rm[..., 1:] = rm[..., :-1].clone()
+        rm[..., 0] = False
+        logits[si[rm]] = -float("inf")
+    return logits

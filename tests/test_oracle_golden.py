@@ -312,3 +312,23 @@ def test_bert_tokenizer_matches_reference(full, tmp_path):
     assert tok.tokenize("   ") == [] and tok.tokenize("") == []
     with pytest.raises(FileNotFoundError):
         optimus_bert_tokenizer(vocab_file="/nonexistent/vocab.txt").tokenize("a")
+
+
+@pytest.mark.parametrize("top_k,top_p", [(0, 1.0), (5, 1.0), (0, 0.9), (0, 0.3), (40, 0.8), (1, 0.5), (1000, 0.99)])
+def test_top_k_top_p_filter_equals_reference_rule(top_k, top_p):
+    """The product filters the PROBABILITY vector (lib/model_zoo/optimus.top_k_top_p_filtering) where the reference
+    filters logits (optimus.py:690-721): the sampling distribution softmax(filtered logits) must be the same."""
+    from lib.model_zoo.optimus import top_k_top_p_filtering as mine
+    from oracle import optimus_oracle as OO
+    g = torch.Generator().manual_seed(top_k * 7 + int(top_p * 100))
+    for temperature in (1.0, 0.7):
+        logits = torch.randn(300, generator=g) * 3.0 / temperature
+        ref = torch.softmax(OO.top_k_top_p_filtering(logits, top_k=top_k, top_p=top_p), dim=-1)
+        p = mine(torch.softmax(logits, dim=-1), top_k=top_k, top_p=top_p)
+        p = p / p.sum()
+        if top_p >= 1.0:   # the reference's `cumulative > 1.0` fires on fp32 round-off in the far tail only: the product skips it
+            differ = (p > 0) != (ref > 0)
+            assert float(p[differ].sum()) < 1e-5 and torch.allclose(p, ref, rtol=0, atol=1e-6)
+            continue
+        assert torch.equal(p > 0, ref > 0)
+        assert torch.allclose(p, ref, rtol=1e-5, atol=1e-8)
