@@ -348,7 +348,7 @@ def main():
             if args.dump_kernel_table:
                 with open(args.dump_kernel_table, "w") as f:
                     json.dump(table, f, indent=1, sort_keys=True)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_leg(net, device)
         print(json.dumps(out))
     if distributed:
