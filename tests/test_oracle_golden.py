@@ -332,3 +332,48 @@ def test_top_k_top_p_filter_equals_reference_rule(top_k, top_p):
             continue
         assert torch.equal(p > 0, ref > 0)
         assert torch.allclose(p, ref, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/lib/model_zoo/optimus_models/vocab/gpt2-vocab.json"),
+                    reason="reference checkout (tokenizers + published vocabularies) not present")
+def test_tokenizers_against_live_reference_on_random_strings():
+    """300 seeded random strings (ASCII words, digits, punctuation runs, accents, CJK, emoji, odd whitespace, control
+    characters, contractions) through the REFERENCE's own BERT and GPT-2 tokenizers (separate process,
+    oracle/ref_tokenize.py) and through the product's re-implementations: identical pieces / ids / decoded text."""
+    import random
+    import subprocess
+    import sys
+    from lib.model_zoo.optimus import optimus_bert_tokenizer, optimus_gpt2_tokenizer
+    rnd = random.Random(20260924)
+    words = ["the", "a", "Photo", "of", "cat", "sitting", "don't", "it's", "I'm", "we've", "they're", "can not", "do not",
+             "unaffable", "naïve", "café", "São", "Zürich", "山", "水", "画", "日本語", "☕", "🙂", "12:30", "3.14", "#42", "e-mail",
+             "U.S.A.", "o'keeffe", "(oil)", "[x]", "{y}", "a/b", "50%", "$5", "x_y", "--", "...", "?!", "\t", "\n", "\u00a0", "\u2009",
+             "\x07", "\ufffd", "Ωmega", "straße", "İstanbul", "supercalifragilisticexpialidocious", "aaaaaaaaaa" * 11]
+    seps = [" ", " ", " ", "  ", ", ", ". ", "! ", "\t", "\n", "", "-", "' "]
+    texts = []
+    for _ in range(300):
+        n = rnd.randint(1, 9)
+        t = ""
+        for _ in range(n):
+            t += rnd.choice(words) + rnd.choice(seps)
+        texts.append(t.strip() if rnd.random() < 0.5 else t)
+    texts += ["", " ", "a", "A", ".", "hello world", "Hello, World!"]
+    texts = [t for t in texts if t.strip()]        # whitespace-only input: documented difference (reference emits a random special token)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_tokenize.py")], input=json.dumps(texts),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("{"):])
+    v = "/root/reference/lib/model_zoo/optimus_models/vocab/"
+    bert = optimus_bert_tokenizer(vocab_file=v + "bert-base-cased-vocab.txt", do_lower_case=False, max_len=512)
+    gpt2 = optimus_gpt2_tokenizer(vocab_file=v + "gpt2-vocab.json", merges_file=v + "gpt2-merges.txt")
+    gpt2.add_special_tokens({"pad_token": "<PAD>", "bos_token": "<BOS>", "eos_token": "<EOS>"})
+    bad = []
+    for i, t in enumerate(texts):
+        if bert.tokenize(t) != ref["bert"][i]:
+            bad.append(("bert", t, bert.tokenize(t), ref["bert"][i]))
+        ids = gpt2.encode(t)
+        if ids != ref["gpt2"][i]:
+            bad.append(("gpt2", t, ids, ref["gpt2"][i]))
+        elif gpt2.decode(ids, clean_up_tokenization_spaces=True) != ref["gpt2_decoded"][i]:
+            bad.append(("gpt2-decode", t, gpt2.decode(ids, clean_up_tokenization_spaces=True), ref["gpt2_decoded"][i]))
+    assert not bad, bad[:3]
