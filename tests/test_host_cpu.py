@@ -77,6 +77,36 @@ def test_reference_yaml_files_load_unchanged(monkeypatch):
         assert mine.args[k] == ref.args[k]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs/model"), reason="reference checkout not present")
+def test_every_model_name_resolves_like_the_reference_bank():
+    """All 27 model names of the reference's configs/model/*.yaml, resolved by the REFERENCE's own model_cfg_bank from its
+    own files (separate process, oracle/ref_cfg_dump.py) and by this package's bank from this package's YAML files:
+    identical resolved trees (type, args after super_cfg merging, MODEL() expansion, pth / hfm sources)."""
+    import subprocess
+    import sys
+    import yaml
+    from lib.cfg_helper import model_cfg_bank
+    names = []
+    for fn in sorted(os.listdir("/root/reference/configs/model")):
+        if fn.endswith(".yaml"):
+            names += list(yaml.safe_load(open(os.path.join("/root/reference/configs/model", fn))))
+    assert len(names) == 27
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_cfg_dump.py")] + names, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index("{"):])
+
+    def plain(o):
+        if isinstance(o, dict):
+            return {str(k): plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return o
+
+    for name in names:
+        mine = json.loads(json.dumps(plain(model_cfg_bank()(name)), sort_keys=True))
+        assert mine == ref[name], name
+
+
 def test_state_dict_layout_matches_reference():
     """Keys and shapes equal those of the reference modules (recorded by oracle/gen_golden.py)."""
     from lib.model_zoo import get_model
