@@ -107,6 +107,31 @@ def test_every_model_name_resolves_like_the_reference_bank():
         assert mine == ref[name], name
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
+def test_full_size_state_dict_layouts_equal_the_reference_modules():
+    """FULL-size modules of the checkpoint (2-D UNet, 0-D UNet with data+context / context-only blocks, KL-f8 VAE, Optimus
+    BERT encoder and GPT-2 decoder), built on the meta device by the REFERENCE's registry from its own configs (separate
+    process, oracle/ref_state_dict_dump.py) and by this package: same state-dict keys, same shapes -- what loading
+    vd-four-flow-v1-0[-fp16].pth / kl-f8.pth / optimus-vae.pth relies on."""
+    import subprocess
+    import sys
+    from lib.cfg_helper import model_cfg_bank
+    from lib.model_zoo import get_model
+    names = ["openai_unet_2d_v1", "openai_unet_0d_v1_dc", "openai_unet_0d_v1_c", "autokl_v1", "optimus_bert_encoder", "optimus_gpt2_decoder"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_state_dict_dump.py")] + names, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index('{"'):])
+    for name in names:
+        cfg = model_cfg_bank()(name)
+        for k in ("pth", "ckpt", "hfm"):
+            cfg.pop(k, None)
+        with torch.device("meta"):
+            net = get_model()(cfg, verbose=False)
+        mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert mine == ref[name], (name, sorted(set(mine) ^ set(ref[name]))[:5])
+    assert len(ref["openai_unet_2d_v1"]) == 686
+
+
 def test_state_dict_layout_matches_reference():
     """Keys and shapes equal those of the reference modules (recorded by oracle/gen_golden.py)."""
     from lib.model_zoo import get_model
