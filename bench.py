@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="run only the cpu_baseline leg (VD_CPU_THREADS selects the pinned thread count) and print it")
     ap.add_argument("--dump-kernel-table", default=None, help="write the per-kernel table of the roofline leg here")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -285,6 +287,9 @@ def main():
 
     from lib.model_zoo.ddim import DDIMSampler
     net = build_model(device)
+    if args.cpu_baseline_only:
+        print(json.dumps({"cpu_baseline": cpu_baseline_leg(net, device)}))
+        return
     sampler = DDIMSampler(net)
     ctxs = make_contexts(wl, n_global, device, 1000)   # same seed on every rank: the full batch, sliced per rank
     images = None
