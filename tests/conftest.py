@@ -35,3 +35,15 @@ def pytest_collection_modifyitems(config, items):
 def dev():
     import torch
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _pin_oracle_threads():
+    """The fp32 CPU oracle is what the long GPU parity tests wait for.  On the GPU boxes' 256-thread hosts torch's default
+    thread count oversubscribes it (one CFG-batch-2 UNet forward: 4.2 s on 16 threads, 6.3 s on 64, 11.2 s on 128 --
+    measured through bench.py --cpu-baseline-only), so the oracle runs on 16 pinned threads there."""
+    if _has_gpu():
+        import torch
+        n = int(os.environ.get("VD_CPU_THREADS", "16"))
+        torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
+    yield
