@@ -132,6 +132,61 @@ def test_full_size_state_dict_layouts_equal_the_reference_modules():
     assert len(ref["openai_unet_2d_v1"]) == 686
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
+def test_schedule_helpers_bit_exact_against_live_reference_over_a_grid():
+    """make_beta_schedule / make_ddim_timesteps / make_ddim_sampling_parameters of this package against the REFERENCE's own
+    functions (separate process, oracle/ref_schedules.py): every DDIM step count 1..120 plus 200 / 250 / 500 / 1000, both
+    discretisations, eta in {0, 0.25, 1}, the reference fed its model's fp32 alphas_cumprod buffer as its sampler does.
+    Betas, timesteps, alphas and alphas_prev bit-exact; sigmas (eta > 0 only) to 2e-5 relative: the reference evaluates
+    that one formula on a mix of an fp32 torch tensor and float64 numpy arrays whose promotion even depends on the array
+    length, this package evaluates it in float64; the same exception type where the reference raises."""
+    import subprocess
+    import sys
+    from lib.model_zoo import diffusion_utils as du
+    grid = {"steps": list(range(1, 121)) + [200, 250, 500, 1000], "etas": [0.0, 0.25, 1.0], "methods": ["uniform", "quad"],
+            "schedules": [["linear", 1000, 0.00085, 0.012], ["linear", 1000, 1e-4, 2e-2], ["linear", 250, 0.0015, 0.0195],
+                          ["cosine", 1000, 1e-4, 2e-2], ["sqrt_linear", 1000, 1e-4, 2e-2], ["sqrt", 1000, 1e-4, 2e-2]]}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_schedules.py")], input=json.dumps(grid),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = json.loads(r.stdout[r.stdout.index('{"'):])
+
+    def same(mine, e, what):
+        a = np.asarray(mine)
+        assert str(a.dtype) == e["dtype"] and list(a.shape) == e["shape"] and a.tobytes().hex() == e["hex"], what
+
+    for name, n, a, b in grid["schedules"]:
+        key = "%s/%d/%r/%r" % (name, n, a, b)
+        same(np.asarray(du.make_beta_schedule(name, n, linear_start=a, linear_end=b)), ref["betas"][key], key)
+    betas = np.asarray(du.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012))
+    alphacums = np.cumprod(1.0 - betas, axis=0).astype(np.float32)
+
+    def dec(e):
+        return np.frombuffer(bytes.fromhex(e["hex"]), dtype=e["dtype"]).reshape(e["shape"])
+
+    for method in grid["methods"]:
+        for s_ in grid["steps"]:
+            e = ref["ddim"]["%s/%d" % (method, s_)]
+            if "error" in e:
+                with pytest.raises(Exception) as ei:
+                    du.make_ddim_timesteps(method, s_, 1000, verbose=False)
+                assert type(ei.value).__name__ == e["error"], (method, s_)
+                continue
+            ts = du.make_ddim_timesteps(method, s_, 1000, verbose=False)
+            same(ts, e["timesteps"], (method, s_))
+            for eta in grid["etas"]:
+                ee = e["eta%r" % eta]
+                if isinstance(ee, dict):
+                    with pytest.raises(Exception) as ei:
+                        du.make_ddim_sampling_parameters(alphacums, ts, eta, verbose=False)
+                    assert type(ei.value).__name__ == ee["error"], (method, s_, eta)
+                    continue
+                sig, al, alp = du.make_ddim_sampling_parameters(alphacums, ts, eta, verbose=False)
+                same(al, ee[1], (method, s_, eta, "alpha"))
+                same(alp, ee[2], (method, s_, eta, "alpha_prev"))
+                assert np.allclose(sig, dec(ee[0]), rtol=2e-5 if s_ > 1 else 2e-3, atol=0), (method, s_, eta, "sigma")
+
+
 def test_state_dict_layout_matches_reference():
     """Keys and shapes equal those of the reference modules (recorded by oracle/gen_golden.py)."""
     from lib.model_zoo import get_model
