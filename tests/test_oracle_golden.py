@@ -377,3 +377,47 @@ def test_tokenizers_against_live_reference_on_random_strings():
         elif gpt2.decode(ids, clean_up_tokenization_spaces=True) != ref["gpt2_decoded"][i]:
             bad.append(("gpt2-decode", t, gpt2.decode(ids, clean_up_tokenization_spaces=True), ref["gpt2_decoded"][i]))
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
+def test_oracle_against_live_reference_on_random_cases(tiny_sd, meta, tmp_path):
+    """Beyond the fixed fixtures: 8 seeded random cases (batch 1-3, 8/16/24-pixel ragged latents, context lengths 3-89,
+    random timesteps, mixing ratios, guidance scales, step counts; single-context, two-context and partial-schedule DDIM
+    loops) run through the LIVE reference in a separate process (oracle/ref_live_cases.py) and replayed through the
+    oracle: forwards < 1e-5, final latents < 1e-4 rel-L2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "live.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "ref_live_cases.py"), out, "20260924", "8"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(out)
+    plan = O.unet_plan(**meta["unet2d"])
+    flavours = set()
+    for k in range(int(d["n"])):
+        g = lambda n: T(d["%d_%s" % (k, n)])
+        ratio, steps, scale, flavour, fwd = [float(v) for v in d["%d_meta" % k]]
+        x, t, ct, ci = g("x"), g("t").long(), g("ct"), g("ci")
+        with torch.no_grad():
+            assert rel(O.apply_model(tiny_sd, plan, x, t, ct, c_type="text", global_ptr="image"), g("e_t")) < 1e-5, k
+            assert rel(O.apply_model(tiny_sd, plan, x, t, ci, c_type="image", global_ptr="image"), g("e_i")) < 1e-5, k
+            mix = O.apply_model_multicontext(tiny_sd, plan, x, t, [("text", ct, ratio), ("image", ci, 1.0 - ratio)], global_ptr="image")
+            assert rel(mix, g("e_m")) < 1e-5, k
+            c_text = {"type": "text", "conditioning": ct, "unconditional_conditioning": g("ut"), "ratio": ratio}
+            c_img = {"type": "image", "conditioning": ci, "unconditional_conditioning": torch.zeros_like(ci), "ratio": 1.0 - ratio}
+            flavours.add(int(flavour))
+            if int(flavour) == 0:
+                z, _ = O.ddim_sample(tiny_sd, plan, tiny_sd["alphas_cumprod"], g("xT"), [dict(c_text, ratio=1.0)], int(steps), scale,
+                                     global_ptr="image")
+            elif int(flavour) == 1:
+                z, _ = O.ddim_sample(tiny_sd, plan, tiny_sd["alphas_cumprod"], g("xT"), [c_text, c_img], int(steps), scale,
+                                     global_ptr="image")
+            else:
+                sched = O.ddim_schedule(tiny_sd["alphas_cumprod"], int(steps), 0.0)
+                tq = torch.full((x.shape[0],), int(sched["timesteps"][int(fwd)]), dtype=torch.long)
+                x_start = O.q_sample(tiny_sd, x, tq, g("xT"))
+                z, _ = O.ddim_sample(tiny_sd, plan, tiny_sd["alphas_cumprod"], x_start, [dict(c_img, ratio=1.0)], int(steps), scale,
+                                     global_ptr="image", forward_steps=int(fwd))
+            assert rel(z, g("z")) < 1e-4, (k, flavour)
+    assert flavours == {0, 1, 2}
