@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: seeded RANDOM cases through the live REFERENCE (tiny VD_v2_0 of oracle/gen_golden.py, synthetic
 weights): apply_model with a text / image context, apply_model_multicontext with random ratios, ragged geometries, and
-guided / unguided / multi-context / partial-schedule DDIM loops with the start latent injected.  Writes an .npz with the
+guided / unguided / multi-context / partial-schedule DDIM loops with the start latent injected, KL-f8 encode / decode at
+random image sizes, the text-latent (0-D) flow.  Writes an .npz with the
 inputs and the reference outputs; the CPU test replays the inputs through the oracle.  Separate process (the reference
 package is also called `lib`); needs /root/reference.      usage: python oracle/ref_live_cases.py out.npz seed n_cases"""
 import os
@@ -39,7 +40,7 @@ def main():
             # DDIM: steps / scale / flavour at random; start latent (or forward-process noise) injected
             steps = int(rng.choice([4, 5, 6, 7, 10]))
             scale = float(rng.choice([1.0, 3.0, 7.5]))
-            flavour = int(rng.randint(0, 3))          # 0 single text ctx, 1 two contexts, 2 partial schedule from x0
+            flavour = k % 3                           # 0 single text ctx, 1 two contexts, 2 partial schedule from x0
             ut = G.seeded((1, Lt, 128), 400 + k, 0.5).repeat(B, 1, 1)
             ui = torch.zeros_like(ci)
             xT = G.seeded((B, 4, H, W), 500 + k)
@@ -57,6 +58,19 @@ def main():
                     fwd = int(rng.randint(1, steps))
                     z, _ = sampler.sample(steps=steps, shape=[B, 4, H, W], x_info={"type": "image", "x0": x, "x0_forward_timesteps": fwd},
                                           c_info=c_img, eta=0.0, verbose=False)    # q_sample noise = xT (injected)
+            # KL-f8 VAE on a random image size (encode up to the moments, decode of a random latent through vae_decode's
+            # 1/scale) and the text-latent (0-D) flow with either context type
+            Hi, Wi = int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, 48]))
+            img = torch.rand((B, 3, Hi, Wi), generator=torch.Generator().manual_seed(600 + k))
+            zl = G.seeded((B, 4, Hi // 2, Wi // 2), 700 + k)
+            x0d = G.seeded((B, 128), 800 + k)
+            with torch.no_grad():
+                mom = net.vae["image"].encode(img, out_posterior=True).parameters
+                dec = net.vae_decode(zl, which="image")
+                e0_i = net.apply_model({"type": "text", "x": x0d}, t, {"type": "image", "c": ci})
+                e0_t = net.apply_model({"type": "text", "x": x0d}, t, {"type": "text", "c": ct})
+            for name, v in (("img", img), ("zl", zl), ("mom", mom), ("dec", dec), ("x0d", x0d), ("e0_i", e0_i), ("e0_t", e0_t)):
+                out["%d_%s" % (k, name)] = v.numpy()
             for name, v in (("x", x), ("t", t), ("ct", ct), ("ci", ci), ("e_t", e_t), ("e_i", e_i), ("e_m", e_m), ("ut", ut), ("xT", xT), ("z", z)):
                 out["%d_%s" % (k, name)] = v.numpy()
             out["%d_meta" % k] = np.array([r, steps, scale, flavour, fwd], dtype=np.float64)

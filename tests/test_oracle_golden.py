@@ -383,7 +383,7 @@ def test_tokenizers_against_live_reference_on_random_strings():
 def test_oracle_against_live_reference_on_random_cases(tiny_sd, meta, tmp_path):
     """Beyond the fixed fixtures: 8 seeded random cases (batch 1-3, 8/16/24-pixel ragged latents, context lengths 3-89,
     random timesteps, mixing ratios, guidance scales, step counts; single-context, two-context and partial-schedule DDIM
-    loops) run through the LIVE reference in a separate process (oracle/ref_live_cases.py) and replayed through the
+    loops; KL-f8 encode / decode at random image sizes; the text-latent flow) run through the LIVE reference in a separate process (oracle/ref_live_cases.py) and replayed through the
     oracle: forwards < 1e-5, final latents < 1e-4 rel-L2."""
     import subprocess
     import sys
@@ -420,4 +420,11 @@ def test_oracle_against_live_reference_on_random_cases(tiny_sd, meta, tmp_path):
                 z, _ = O.ddim_sample(tiny_sd, plan, tiny_sd["alphas_cumprod"], x_start, [dict(c_img, ratio=1.0)], int(steps), scale,
                                      global_ptr="image", forward_steps=int(fwd))
             assert rel(z, g("z")) < 1e-4, (k, flavour)
+            dd = meta["vae"]["ddconfig"]
+            kw = dict(ch_mult=dd["ch_mult"], num_res_blocks=dd["num_res_blocks"])
+            assert rel(O.vae_encode_moments(tiny_sd, "vae.image", g("img"), **kw), g("mom")) < 1e-5, k
+            assert rel(O.vae_decode(tiny_sd, "vae.image", g("zl") * (1.0 / 0.18215), **kw), g("dec")) < 1e-5, k
+            p0d = O.unet0d_plan(**meta["unet0d"])
+            assert rel(O.apply_model(tiny_sd, p0d, g("x0d"), t, ci, x_type="text", c_type="image", global_ptr="image"), g("e0_i")) < 1e-5, k
+            assert rel(O.apply_model(tiny_sd, p0d, g("x0d"), t, ct, x_type="text", c_type="text", global_ptr="image"), g("e0_t")) < 1e-5, k
     assert flavours == {0, 1, 2}
