@@ -428,3 +428,32 @@ def test_oracle_against_live_reference_on_random_cases(tiny_sd, meta, tmp_path):
             assert rel(O.apply_model(tiny_sd, p0d, g("x0d"), t, ci, x_type="text", c_type="image", global_ptr="image"), g("e0_i")) < 1e-5, k
             assert rel(O.apply_model(tiny_sd, p0d, g("x0d"), t, ct, x_type="text", c_type="text", global_ptr="image"), g("e0_t")) < 1e-5, k
     assert flavours == {0, 1, 2}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
+def test_optimus_oracle_against_live_reference_on_random_cases(tmp_path):
+    """GPT-2 latent-connector logits (random sequence lengths 1-19, batches 1-3) and BERT latent-connector outputs (random
+    right-padded batches, lengths 2-29, incl. rows without padding) from the LIVE reference classes (separate process,
+    oracle/ref_live_optimus.py) against oracle/optimus_oracle.py."""
+    import subprocess
+    import sys
+    from oracle import optimus_oracle as OO
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "lo.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "ref_live_optimus.py"), out, "31", "6"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(out)
+    meta_o, cfg, net, sd = _optimus_sd()
+    mb = _bert_meta()
+    from lib.model_zoo.optimus import optimus_bert_connector
+    bnet = optimus_bert_connector(mb["config"], latent_size=mb["config"]["latent_size"])
+    bsd = synth.synth_state_dict({"encoder." + k: v for k, v in synth.shapes_of(bnet).items()}, mb["seed"])
+    for k in range(int(d["n"])):
+        lg = OO.gpt2_logits(sd, "decoder", T(d["%d_gpt_ids" % k]).long(), T(d["%d_gpt_z" % k]), cfg["n_head"], cfg["n_layer"])
+        assert rel(lg, d["%d_gpt_logits" % k]) < 1e-5, k
+        ids = T(d["%d_bert_ids" % k]).long()
+        seq, pooled = OO.bert_forward(bsd, "encoder", ids, (ids > 0).float(), mb["config"]["num_attention_heads"],
+                                      mb["config"]["num_hidden_layers"])
+        assert rel(seq, d["%d_bert_seq" % k]) < 1e-5 and rel(pooled, d["%d_bert_pooled" % k]) < 1e-5, k
+        assert rel(OO.bert_latent_mu(bsd, "encoder", pooled), d["%d_bert_mu" % k]) < 1e-5, k
