@@ -112,6 +112,15 @@ int vd_gemm_num_configs(void);
 /* Development hook (tools/gemm_sweep.py, A/B runs): force every following vd_gemm_f16 of this process onto tile_cfg
  * (-1 = planner's choice) where the shape permits.  Process-global and unsynchronised: not for production use. */
 int vd_gemm_set_override(int tile_cfg);
+/* 3x3 / stride 1 / pad 1 convolutions (VdGemmDesc.ksize = 3) whose output grid tiles into 8 x 32 pixel patches run on
+ * conv3x3_halo_kernel: the (rows + 2) x (cols + 2) input halo of a patch is staged in LDS once per 64-channel chunk and the
+ * nine taps read shifted views of it, instead of gemm_f16_kernel's nine gathers (ResBlock / Upsample / VAE convs:
+ * lib/model_zoo/openaimodel.py:89-117,254-274, autokl_modules.py:82-141).  vd_gemm_plan reports these launches as
+ * tile_cfg = vd_gemm_num_configs() + variant, 0 <= variant < VD_CONV_HALO_VARIANTS (vd_gemm_config_name knows them).
+ * Development hook: -1 = planner's choice (default; also the environment variable VD_CONV_HALO), 0 = never (every conv on
+ * gemm_f16_kernel), k > 0 = force variant k - 1 where the geometry permits.  Process-global like vd_gemm_set_override. */
+#define VD_CONV_HALO_VARIANTS 8
+int vd_conv_halo_set_variant(int setting);
 /* Tuned launch table: a problem (M, N, K, ksize, epilogue class: bit 0 GEGLU, bit 1 LayerNorm fold, bit 2 two-source A) is
  * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table
  * (lib/gemm_tune.py) from a file tools/tune_forward.py measured inside a UNet forward -- the setting that decides, since

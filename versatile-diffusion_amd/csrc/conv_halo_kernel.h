@@ -1,0 +1,499 @@
+// Halo-resident 3x3 convolution (stride 1, pad 1, optional nearest-2x upsample in front, optional two-source channel
+// concat) as an MFMA implicit GEMM for gfx950.  Included by conv_halo.hip (two waves per SIMD) and conv_halo_big.hip
+// (one wave per SIMD).
+//
+//   out[pixel][n] = epilogue( sum_{tap, c} X[pixel + tap][c] * W[n][tap][c] )
+//
+// Replaces the 3x3 nn.Conv2d of ResBlock.in_layers / out_layers, Upsample.conv and the VAE ResnetBlocks
+// (/root/reference/lib/model_zoo/openaimodel.py:89-117,254-274, autokl_modules.py:82-141) on the shapes it accepts;
+// everything else (stride 2, ragged grids, tiny Cout) stays on gemm_f16_kernel, whose gather re-fetches the activation
+// tile for every one of the 9 taps (gemm_kernel.h: issue_begin).
+//
+// What is different from gemm_f16_kernel:
+//   * a block owns BM output pixels that form an 8-row x 32-column patch of one image (or whole small images), and walks
+//     the input channels in chunks of 64.  For a chunk the (rows + 2) x (cols + 2) pixel HALO of the patch is brought into
+//     LDS ONCE by LDS-DMA ([halo pixel][64 channels], 128 bytes per pixel, 16-byte slots XOR-swizzled with the pixel index
+//     on the source side); the 9 taps are 9 shifted views of that image: the fragment read of tap (ky, kx) is the same
+//     ds_read_b128 at pixel + ky * pitch + kx.  Activation bytes through L2 -> LDS drop by 9 * BM / halo = 6.8x (256-pixel
+//     patches: 340 halo pixels instead of 9 x 256); zero padding is the buffer descriptor's out-of-range read.
+//   * only the weight tile [BN][64] of the current (chunk, tap) streams per K tile, so the DMA volume per MFMA is what a
+//     (2.2 x larger) plain tile would need, and BM can be 256 pixels at BN = 160: N = 320 / 640 / 1280 are covered without
+//     padding columns and a 64x64-latent conv is exactly one block per CU.
+//   * the halo of the NEXT chunk arrives in 1-KiB pieces spread over the taps of the current one (double-buffered).
+//   * MODE 0: one barrier at the top of every tap (wait for the tap's weight tile, issue the next), 2 weight stages.
+//     MODE 1: the barrier sits in the MIDDLE of a tap, 3 weight stages, and operand fragments are requested one k-step ahead
+//     with two named register sets -- nothing a wave needs right after the barrier depends on it (the second half of the
+//     tap reads a stage published by the previous barrier), so the matrix pipe does not drain at tap boundaries.
+//   * split-K runs over channel chunks (fp32 slabs + splitk_reduce_kernel of gemm.hip).
+// Epilogue (bias / activation / alpha in registers, tile staged through LDS, 16-byte row segments + per-image row vector +
+// residual on the way out) follows gemm_f16_kernel; output rows are mapped from patch order back to pixel order.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace {
+
+// compile-time loop: f(std::integral_constant<int, LO>{}) ... f(std::integral_constant<int, HI - 1>{})
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
+struct ConvHaloArgs {
+    GemmArgs g;                     // descriptor as validated / normalised by plan_gemm (gemm.hip) + operand extents
+    int ltw, tw, rg, ngrp, lgsz;    // patch: tw columns (log2 ltw) x rg rows per group, ngrp groups (images), lgsz = log2(tw * rg)
+    int pitch, gpx, hpx;            // halo: pixels per row (tw + 2), per group ((rg + 2) * pitch), in total
+    int mg_pitch, mg_gpx;           // 2^20 / d + 1 magic numbers of the two divisions (operands < 2^20 / d)
+    int tiles_x, tiles_y;           // patches per image (ngrp == 1)
+    int nchunks, chunks_per_split;  // 64-channel chunks of the (concatenated) input
+    int Hv, Wv;                     // (virtual, i.e. upsampled) image size == output size
+    int halo_bytes;                 // one halo buffer: hpx rounded up to whole 8-pixel DMA pieces, x 128
+};
+
+// MODE 0 / 1 as above.  NT = 64 * waves; wave grid (BM / WM) x (BN / WN), wave tile WM pixels x WN channels.
+template <int BM, int BN, int WM, int WN, int NT, int MODE>
+__global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHaloArgs p) {
+    constexpr int NW = NT / 64;
+    constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+    static_assert(WAVES_M * WAVES_N == NW, "waves must tile the block");
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int WST = MODE == 0 ? 2 : 3;              // weight stages
+    constexpr bool PIN = MODE == 2;                     // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
+    constexpr int WSTAGE = BN * 128;                    // bytes of one weight tile [BN][64]
+    constexpr int NPW = BN / 8;                         // 1-KiB DMA pieces (8 rows) of a weight tile
+    constexpr int WPW = (NPW + NW - 1) / NW;            // ... per wave
+    constexpr int HPXMAX = BM * 100 / 64 + 16;          // bound on halo pixels (checked by the launcher)
+    constexpr int NHP = (HPXMAX + 7) / 8;               // halo pieces of 8 pixels
+    constexpr int HPW = (NHP + NW - 1) / NW;            // ... per wave and chunk
+    constexpr int HPT = (HPW + 7) / 8;                  // ... per wave and tap (taps 0..7 carry them)
+    constexpr int MAXHP = HPT * 8;
+    constexpr int CS_LD = BN + 8;                       // fp16 epilogue tile leading dimension
+    static_assert(BN % 8 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const VdGemmDesc& d = p.g.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- XCD-aware tile mapping (as gemm_f16_kernel): an XCD gets a contiguous run of tiles, n fastest, so the column
+    // tiles of one patch (same halo) and neighbouring patches (shared halo rows) meet in one L2
+    const int ntiles = p.g.tiles_m * p.g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.g.tiles_n, tn = bid - tm * p.g.tiles_n;
+    const int n0 = tn * BN;
+    const int split = blockIdx.y;
+
+    // patch origin
+    int img0, y0, x0;
+    if (p.ngrp == 1) {
+        const int tpi = p.tiles_x * p.tiles_y;
+        img0 = tm / tpi;
+        const int r = tm - img0 * tpi;
+        const int ty = r / p.tiles_x;
+        y0 = ty * p.rg;
+        x0 = (r - ty * p.tiles_x) * p.tw;
+    } else {
+        img0 = tm * p.ngrp;
+        y0 = 0;
+        x0 = 0;
+    }
+
+    const i32x4 ws_a0 = make_rsrc_words(d.a0, p.g.a0_bytes);
+    const i32x4 ws_a1 = make_rsrc_words(d.a1 ? d.a1 : d.a0, d.a1 ? p.g.a1_bytes : 0u);
+    const i32x4 ws_w = make_rsrc_words(d.w, p.g.w_bytes);
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned w_lds0 = lds0 + 2u * (unsigned)p.halo_bytes;
+    const char* const w_smem = smem + 2 * p.halo_bytes;
+
+    // ---- per-lane source of the halo pieces this wave issues: piece q = j * NW + wave covers halo pixels 8q .. 8q + 7,
+    // lane = (pixel in piece) * 8 + physical 16-byte slot; the lane fetches the LOGICAL slot that lives there (swizzle on
+    // the source side, the DMA destination is lane-linear).  Packed as (input pixel index << 3 | logical slot), -1 = zeros.
+    int hsrc[MAXHP];
+#pragma unroll
+    for (int j = 0; j < MAXHP; ++j) {
+        const int hp = (j * NW + wave) * 8 + (lane >> 3);
+        const int grp = (hp * p.mg_gpx) >> 20;
+        const int rem = hp - grp * p.gpx;
+        const int hy = (rem * p.mg_pitch) >> 20;
+        const int hx = rem - hy * p.pitch;
+        const int vy = y0 + hy - 1, vx = x0 + hx - 1;
+        const bool ok = hp < p.hpx && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv;
+        const int pix = ((img0 + grp) * d.Hin + (vy >> d.ups)) * d.Win + (vx >> d.ups);
+        const int slot = (lane & 7) ^ ((hp >> 1) & 7);
+        hsrc[j] = ok ? ((pix << 3) | slot) : -1;
+    }
+    // weight pieces: piece q = j * NW + wave covers tile rows 8q .. 8q + 7
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
+        const int n = n0 + r;
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        wvoff[j] = (r < BN && n < d.N) ? (unsigned)((n * d.ldw + slot * 8) * 2) : OOB_OFFSET;
+    }
+
+    const int ctot = d.c0 + d.c1;
+    const int c_begin = split * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > p.nchunks) c_end = p.nchunks;
+    const int ncl = c_end - c_begin;   // >= 1 by construction of the launcher
+
+    struct ChunkSrc { i32x4 rs; int ld2; unsigned soff; };
+    auto chunk_src = [&](int c) {   // which tensor / channel offset a 64-channel chunk of the concatenation comes from
+        ChunkSrc s;
+        const int cc = c * 64;
+        const bool second = cc >= d.c0;
+        s.rs = second ? ws_a1 : ws_a0;
+        s.ld2 = (second ? d.lda1 : d.lda0) * 2;
+        s.soff = (unsigned)((second ? cc - d.c0 : cc) * 2);
+        return s;
+    };
+    auto issue_halo = [&](auto jt, const ChunkSrc& cs, unsigned buf_lds) {   // piece j of a chunk -> halo buffer at buf_lds
+        constexpr int j = decltype(jt)::value;
+        const int q = j * NW + wave_s;
+        if (q * 8 < p.hpx) {   // wave-uniform
+            const int h = hsrc[j];
+            const unsigned voff = h < 0 ? OOB_OFFSET : (unsigned)((h >> 3) * cs.ld2 + ((h & 7) << 4));
+            dma16(cs.rs, buf_lds + (unsigned)(q * 1024), voff, cs.soff);
+        }
+    };
+    auto issue_w = [&](int c, int tap, int stage) {   // weight tile of (chunk c, tap) -> stage
+        const unsigned soff = (unsigned)((tap * ctot + c * 64) * 2);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int q = j * NW + wave_s;
+            if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + q * 1024), wvoff[j], soff);
+        }
+    };
+
+    // acc[i][j]: TRANSPOSED 32x32 sub-tile (MFMA A operand = weight rows, B operand = pixels): a lane owns output pixel
+    // l31 of fragment i and, per register group g = r >> 2, channels 8g + 4hi + (r & 3) of fragment j.
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // halo pixel of tap (0, 0) for each of the lane's output pixels
+    int hp_base[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wm * WM + i * 32 + l31;
+        const int grp = m >> p.lgsz;
+        const int r = m - (grp << p.lgsz);
+        hp_base[i] = grp * p.gpx + (r >> p.ltw) * p.pitch + (r & (p.tw - 1));
+    }
+    // weight fragment offsets: swizzle key is the same for the NI fragments of a lane (32 rows apart)
+    int rd_w[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd_w[ks] = lds_off_kb<64>(wn * WN + l31, ks * 2 + hi);
+
+    // pixel fragments: byte = hp * 128 + (((2 ks + hi) ^ key) << 4), key = (hp >> 1) & 7, hp = halo pixel of the tap
+    //                       = (hp * 128 + ((hi ^ key) << 4)) ^ (ks << 5): one address per (tap, fragment), one XOR per k-step.
+    // The per-tap addresses are recomputed inside the chunk loop from `hrow` (made opaque per chunk): hoisted out of the
+    // loop they cost 36 registers per fragment, which the operand double-buffering needs more.
+    struct TapAddr { int a0[MI]; };
+    int hrow[MI];
+    auto tap_addr = [&](int halo_off, int tapoff) {   // halo_off: byte offset of the chunk's halo buffer in LDS
+        TapAddr t;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int hp = hrow[i] + tapoff;
+            const int x = ((hp >> 1) & 7) ^ hi;
+            t.a0[i] = halo_off + (hp << 7) + (x << 4);
+        }
+        return t;
+    };
+    auto read_frags = [&](const char* wst, const TapAddr& t, int ks, f16x8* a, f16x8* w) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            U4H8 v;
+            v.u = *reinterpret_cast<const uint4*>(smem + (t.a0[i] ^ (ks << 5)));
+            a[i] = v.h;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            U4H8 v;
+            v.u = *reinterpret_cast<const uint4*>(wst + rd_w[ks] + j * 32 * 128);
+            w[j] = v.h;
+        }
+    };
+    auto mma = [&](const f16x8* a, const f16x8* w) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], a[i], acc[i][j], 0, 0, 0);
+    };
+    auto tapoff_of = [&](int t) { return (t / 3) * p.pitch + (t % 3); };
+
+    // ---- prologue: the whole halo of the first chunk and the first weight tile(s)
+    {
+        const ChunkSrc cs0 = chunk_src(c_begin);
+        static_for<0, MAXHP>([&](auto jt) { issue_halo(jt, cs0, lds0); });
+        issue_w(c_begin, 0, 0);
+        if constexpr (MODE != 0) issue_w(c_begin, 1, 1);
+    }
+
+    if constexpr (MODE == 0) {
+        // ---- one barrier at the top of every tap
+        for (int lc = 0; lc < ncl; ++lc) {
+            const int c = c_begin + lc;
+            const int halo_off = (lc & 1) * p.halo_bytes;
+            const unsigned nxt_halo = lds0 + (unsigned)(((lc & 1) ^ 1) * p.halo_bytes);
+            const bool more = lc + 1 < ncl;
+            const ChunkSrc csn = chunk_src(more ? c + 1 : c);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                hrow[i] = hp_base[i];
+                asm volatile("" : "+v"(hrow[i]));
+            }
+            static_for<0, 9>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                const int stage = (lc & 1) ^ (t & 1);
+                wait_vm<0>();                    // this tap's weight tile (and every older piece) has landed ...
+                __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is done with the previous tap
+                asm volatile("" ::: "memory");
+                if constexpr (t < 8) issue_w(c, t + 1, stage ^ 1);
+                else if (more) issue_w(c + 1, 0, stage ^ 1);
+                if constexpr (t < 8) {
+                    if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
+                }
+                const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
+                const char* wst = w_smem + stage * WSTAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    f16x8 af[MI], wf[NI];
+                    read_frags(wst, ta, ks, af, wf);
+                    mma(af, wf);
+                }
+            });
+        }
+    } else {
+        // ---- barrier in the middle of a tap, fragments one k-step ahead (sets F0 / F1), weight tiles two taps ahead
+        f16x8 a0f[MI], w0f[NI], a1f[MI], w1f[NI];
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MI; ++i) hrow[i] = hp_base[i];
+        {
+            const TapAddr ta = tap_addr(0, 0);
+            read_frags(w_smem, ta, 0, a0f, w0f);
+        }
+        for (int lc = 0; lc < ncl; ++lc) {
+            const int c = c_begin + lc;
+            const int halo_off = (lc & 1) * p.halo_bytes;
+            const unsigned nxt_halo = lds0 + (unsigned)(((lc & 1) ^ 1) * p.halo_bytes);
+            const bool more = lc + 1 < ncl;
+            const ChunkSrc csn = chunk_src(more ? c + 1 : c);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                hrow[i] = hp_base[i];
+                asm volatile("" : "+v"(hrow[i]));
+            }
+            static_for<0, 9>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                constexpr int stage = t % 3;   // (9 lc + t) % 3
+                const char* wst = w_smem + stage * WSTAGE;
+                const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
+                auto pin = [&]() { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); };
+                read_frags(wst, ta, 1, a1f, w1f);
+                pin();
+                mma(a0f, w0f);
+                pin();
+                read_frags(wst, ta, 2, a0f, w0f);
+                pin();
+                mma(a1f, w1f);
+                // the weight tile of the NEXT tap (issued one tap ago) has landed for every wave; every wave has left
+                // the previous tap, whose stage the tile issued below overwrites
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (t + 2 < 9) issue_w(c, t + 2, (t + 2) % 3);
+                else if (more) issue_w(c + 1, t + 2 - 9, (t + 2) % 3);
+                if constexpr (t < 8) {
+                    if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
+                }
+                read_frags(wst, ta, 3, a1f, w1f);
+                pin();
+                mma(a0f, w0f);
+                pin();
+                if constexpr (t < 8) {
+                    const TapAddr tn_ = tap_addr(halo_off, tapoff_of(t + 1));
+                    read_frags(w_smem + ((t + 1) % 3) * WSTAGE, tn_, 0, a0f, w0f);
+                } else if (more) {
+                    const TapAddr tn_ = tap_addr(halo_off ^ p.halo_bytes, 0);
+                    read_frags(w_smem, tn_, 0, a0f, w0f);
+                }
+                pin();
+                mma(a1f, w1f);
+            });
+        }
+    }
+    wait_vm<0>();
+    __syncthreads();   // every wave is done with halo / weight stages: the epilogue tile re-uses that LDS
+
+    const EpiCtx e = make_epi(d, 0);
+    // patch-order row -> output row (pixel index over [image][Hv][Wv])
+    auto out_row = [&](int m) {
+        const int grp = m >> p.lgsz;
+        const int r = m - (grp << p.lgsz);
+        return ((img0 + grp) * p.Hv + y0 + (r >> p.ltw)) * p.Wv + x0 + (r & (p.tw - 1));
+    };
+
+    // ---- split-K: fp32 slabs for splitk_reduce_kernel, straight from registers
+    if (gridDim.y > 1) {
+        float* base = d.ws + (size_t)split * (size_t)d.M * d.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = out_row(wm * WM + i * 32 + l31);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + wn * WN + j * 32 + 8 * g + 4 * hi;
+                    if (col < d.N) {   // N % 8 == 0: whole groups
+                        float* o = base + (size_t)row * d.N + col;
+                        *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                    }
+                }
+        }
+        return;
+    }
+
+    // ---- fused epilogue, part 1 (registers): bias -> act -> * alpha -> fp16 into the LDS tile [BM][CS_LD];
+    // the residual OR row-vector segments of part 2 are requested first so their latency overlaps it
+    f16* cs = reinterpret_cast<f16*>(smem);
+    constexpr int CH = BN / 8;                    // 16-byte segments per tile row
+    constexpr int MAX_CH = BM * CH / NT;
+    static_assert(BM * CH % NT == 0, "segments must divide over the threads");
+    const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
+    const bool want_rv = (e.flags & VD_EPI_ROWVEC) != 0;
+    const bool ld_ok = ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
+    const bool rv_per_image = e.rows_per_batch == p.Hv * p.Wv;
+    auto rv_index = [&](int m, int row) { return rv_per_image ? img0 + (m >> p.lgsz) : row / e.rows_per_batch; };
+    // few segments per thread: request them now; many (one wave per SIMD): read in line, the registers are not there
+    constexpr bool PREFETCH = MAX_CH <= 12;
+    constexpr int NPRE = PREFETCH ? MAX_CH : 1;
+    uint4 pre[NPRE];
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < MAX_CH; ++k) {
+            const int sgm = tid + k * NT;
+            const int r = sgm / CH, col = n0 + (sgm % CH) * 8;
+            const int row = out_row(r);
+            pre[k] = make_uint4(0, 0, 0, 0);
+            if (col < e.N && ld_ok) {
+                if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
+                else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)rv_index(r, row) * e.N + col);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int lrow = wm * WM + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = wn * WN + j * 32 + 8 * g + 4 * hi;
+                const int col = n0 + lc;
+                float bq[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((e.flags & VD_EPI_BIAS) && col < d.N) {
+                    U2H4 t;
+                    t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
+                }
+                U2H4 o;
+                if (e.act == VD_ACT_NONE) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o.e[q] = (f16)((acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o.e[q] = (f16)(apply_act(e.act, acc[i][j][g * 4 + q] + bq[q]) * e.alpha);
+                }
+                *reinterpret_cast<uint2*>(cs + lrow * CS_LD + lc) = o.u;
+            }
+    }
+    __syncthreads();
+
+    // ---- part 2: 16-byte row segments: (+ rowvec) (+ residual) -> global
+#pragma unroll
+    for (int k = 0; k < MAX_CH; ++k) {
+        const int sgm = tid + k * NT;
+        const int r = sgm / CH, cc = (sgm % CH) * 8;
+        const int col = n0 + cc;
+        if (col < e.N) {
+            const int row = out_row(r);
+            U4H8 t, a, b, o;
+            t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+            if (ld_ok) {
+                a.u = make_uint4(0, 0, 0, 0);
+                b.u = make_uint4(0, 0, 0, 0);
+                if constexpr (PREFETCH) {
+                    a.u = pre[k];
+                    if (want_res && want_rv) b.u = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)rv_index(r, row) * e.N + col);
+                } else {
+                    if (want_res) a.u = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
+                    if (want_rv) b.u = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)rv_index(r, row) * e.N + col);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q] + (float)b.e[q]);
+                f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+                if (p.g.nt_store) vd_store16_nt(dst, o.u);
+                else *reinterpret_cast<uint4*>(dst) = o.u;
+            } else {   // unaligned leading dimensions: element-wise tail of gemm_f16_kernel
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (float)t.e[q];
+                epi_finish8(e, row, col, v);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NT, int MODE>
+int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
+    constexpr int WST = MODE == 0 ? 2 : 3;
+    constexpr int EPI = BM * (BN + 8) * 2;
+    const int main_bytes = 2 * a.halo_bytes + WST * BN * 128;
+    const int lds = main_bytes > EPI ? main_bytes : EPI;
+    if (lds > 160 * 1024) {
+        vd_set_error("conv3x3_halo: %d bytes of LDS", lds);
+        return VD_ERR_UNSUPPORTED;
+    }
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            vd_set_error("conv3x3_halo: cannot reserve LDS: %s", hipGetErrorString(e));
+            return VD_ERR_LAUNCH;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    dim3 grid(a.g.tiles_m * a.g.tiles_n, nsplit, 1);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE>), grid, dim3(NT), lds, stream, a);
+    return vd_check_launch("conv3x3_halo");
+}
+
+}  // namespace

@@ -1,8 +1,14 @@
 // vd_gemm_f16: validation, launch planner, the two-waves-per-SIMD instances of the kernel template in
 // gemm_kernel.h and the split-K reduce kernel.  (One-wave-per-SIMD instances: gemm_big.hip.)
 #include "gemm_kernel.h"
+#include "conv_halo_kernel.h"
 #include <mutex>
 #include <vector>
+
+// conv_halo.hip
+int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int* variant_out, int* nsplit_out);
+int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStream_t stream);
+const char* vd_conv_halo_name(int variant);
 
 namespace {
 
@@ -103,7 +109,7 @@ inline int epi_class(const VdGemmDesc& d) {
 }
 
 // validate + normalise the descriptor and pick tile shape / split factor
-int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) {
+int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, ConvHaloArgs* halo = nullptr) {
     VD_REQUIRE(dp != nullptr, "vd_gemm_f16: null descriptor");
     a.d = *dp;
     VdGemmDesc& d = a.d;
@@ -190,6 +196,25 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out) 
         if (ns > 1) t += 3.f + 2.f * ns * (float)d.M * d.N * zb * 4.f / 8.0e6f + 2.f;  // slabs at ~8 TB/s (cache resident) + launch
         return t;
     };
+    // 3x3 convolutions on patch-shaped output grids: the halo-resident kernel (conv_halo.hip), unless a GEMM tile is forced
+    static const bool tile_env = getenv("VD_GEMM_TILE") != nullptr;
+    if (d.ksize == 3 && g_override.load(std::memory_order_relaxed) < 0 && !tile_env) {
+        ConvHaloArgs local;
+        ConvHaloArgs* h = halo ? halo : &local;
+        int hv = 0, hns = 1;
+        if (vd_conv_halo_plan(&a, can_split ? 1 : 0, h, &hv, &hns)) {
+            if (hns > 1) {
+                VD_REQUIRE(d.ws != nullptr, "vd_gemm_f16: split_k=%d needs a workspace", hns);
+                VD_REQUIRE(hns <= VD_MAX_SPLIT_K, "vd_gemm_f16: split_k=%d > %d", hns, VD_MAX_SPLIT_K);
+            }
+            a.tiles_m = h->g.tiles_m;
+            a.tiles_n = h->g.tiles_n;
+            a.kt_per_split = a.kt_total;
+            cfg_out = T_COUNT + hv;
+            nsplit_out = hns;
+            return VD_OK;
+        }
+    }
     TileCfg cfg = T64x64;
     int nsplit = 1;
     if (d.act == VD_ACT_GEGLU) {
@@ -328,6 +353,7 @@ extern "C" int vd_gemm_plan(const VdGemmDesc* dp, int* tile_cfg, int* nsplit) {
 }
 
 extern "C" const char* vd_gemm_config_name(int tile_cfg) {
+    if (tile_cfg >= T_COUNT) return vd_conv_halo_name(tile_cfg - T_COUNT);
     return (tile_cfg >= 0 && tile_cfg < T_COUNT) ? kCfg[tile_cfg].name : nullptr;
 }
 extern "C" int vd_gemm_num_configs(void) { return T_COUNT; }
@@ -355,13 +381,28 @@ extern "C" int vd_gemm_set_override(int tile_cfg) {
 
 extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     GemmArgs a;
+    ConvHaloArgs halo;
     int cfg = 0, nsplit = 1;
-    int rc = plan_gemm(dp, a, cfg, nsplit);
+    int rc = plan_gemm(dp, a, cfg, nsplit, &halo);
     if (rc != VD_OK) return rc;
     const VdGemmDesc& d = a.d;
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    if (cfg >= T_COUNT) {   // halo-resident 3x3 convolution; split-K slabs go through the same reduce kernel
+        halo.g.nt_store = a.nt_store;
+        rc = vd_conv_halo_launch(&halo, cfg - T_COUNT, nsplit, stream);
+        if (rc != VD_OK) return rc;
+        if (nsplit > 1) {
+            a.d.sync = nullptr;
+            const size_t total = (size_t)d.M * ((d.N + 7) / 8);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, 1), dim3(256), 0, stream, a, nsplit);
+            return vd_check_launch("vd_gemm_f16/splitk_reduce");
+        }
+        return VD_OK;
+    }
     if ((long)a.tiles_m * a.tiles_n * zb > VD_GEMM_SYNC_INTS) a.d.sync = nullptr;  // more tiles than counters: two-kernel path
     if (d.flags & VD_EPI_LNFOLD) {
         switch (cfg) {

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "vd_gemm_config_name": (ctypes.c_char_p, [_I]),
     "vd_gemm_num_configs": (_I, []),
     "vd_gemm_set_override": (_I, [_I]),
+    "vd_conv_halo_set_variant": (_I, [_I]),
     "vd_gemm_tune_set": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vd_gemm_tune_clear": (_I, []),
     "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
