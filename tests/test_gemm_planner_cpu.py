@@ -13,10 +13,13 @@ T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
 T128x64d, T64x64d = 14, 15                                   # 3-stage ring for grids that do not fill the chip
 T128x128q, T128x128w8q, T128x320q, T128x160q = 16, 19, 20, 21   # 32-deep K tiles, 4-stage ring: VD_GEMM_VARIANT=q|h only
 T128x64w8, T256x256 = 4, 24
+NCFG = 25                                                    # vd_gemm_num_configs(): classic gemm_f16_kernel instantiations
+H160p, H128p = NCFG + 2, NCFG + 5                            # conv3x3_halo_kernel<256,160,...,2> / <256,128,...,2>
 
 
-def plan(M, N, K, ks=1, B=8, ws=True, act=0):
+def plan(M, N, K, ks=1, B=8, ws=True, act=0, halo=-1):
     from vd_hip.loader import VdGemmDesc, lib
+    assert lib().vd_conv_halo_set_variant(halo) == 0        # 0: 3x3 convs stay on gemm_f16_kernel (the classic planner)
     d = VdGemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a0 = d.w = d.out = 16
@@ -32,28 +35,51 @@ def plan(M, N, K, ks=1, B=8, ws=True, act=0):
 
 
 def test_round_quantisation_drives_the_split():
-    # 160 tiles of 128x128: split 3 = 480 blocks (one round of 512 slots), not split 4 = 640 (two rounds)
-    assert plan(2048, 1280, 11520, ks=3) == (T128x128, 3)
-    assert plan(2048, 1280, 23040, ks=3) == (T128x128, 3)
+    # classic planner (halo kernel off): 160 tiles of 128x128: split 3 = 480 blocks (one round of 512 slots), not split 4 = 640
+    assert plan(2048, 1280, 11520, ks=3, halo=0) == (T128x128, 3)
+    assert plan(2048, 1280, 23040, ks=3, halo=0) == (T128x128, 3)
     # 320 tiles already cover most of a round: no split
-    assert plan(8192, 640, 5760, ks=3) == (T128x128, 1)
-    # 40 tiles at the 8x8 level: deep split
-    cfg, ns = plan(512, 1280, 11520, ks=3)
-    assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
+    assert plan(8192, 640, 5760, ks=3, halo=0) == (T128x128, 1)
+    # 40 tiles at the 8x8 level: deep split (also with the halo kernel on: 16 patches x column tiles are too few for it)
+    for halo in (0, -1):
+        cfg, ns = plan(512, 1280, 11520, ks=3, halo=halo)
+        assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
+
+
+def test_halo_kernel_takes_the_3x3_convolutions():
+    from vd_hip.loader import lib
+    assert lib().vd_gemm_num_configs() == NCFG
+    assert lib().vd_gemm_config_name(H160p) == b"conv3x3_halo_kernel<256,160,32,160,512,2>"
+    # 64x64 level: 128 patches x 2 column tiles = one block per CU, no split
+    for K in (2880, 5760, 8640):
+        assert plan(32768, 320, K, ks=3) == (H160p, 1)
+    # 32x32 level: 32 patches x 4 column tiles: split the channel chunks in two to cover the chip
+    assert plan(8192, 640, 5760, ks=3) == (H160p, 2)
+    assert plan(8192, 640, 2880, ks=3) == (H160p, 2)
+    # 16x16 level: 8 patches (one image each) x 8 column tiles: four ways
+    assert plan(2048, 1280, 11520, ks=3) == (H160p, 4)
+    assert plan(2048, 1280, 23040, ks=3) == (H160p, 4)
+    # no workspace, no split; widths that 160 does not divide but 128 does (VAE): 64x64 wave tiles
+    assert plan(8192, 640, 5760, ks=3, ws=False) == (H160p, 1)
+    assert plan(4 * 64 * 64, 512, 9 * 512, ks=3, B=4) == (H128p, 1)
+    # the 4-channel output head and plain GEMMs never go there
+    assert plan(32768, 4, 2880, ks=3)[0] < NCFG
+    assert plan(32768, 320, 320)[0] < NCFG
 
 
 def test_wide_tile_for_the_64x64_level():
     for K, ks in ((2880, 3), (5760, 3), (1280, 1)):
-        assert plan(32768, 320, K, ks=ks) == (T128x320, 1)     # one block spans all of N: A is read from L2 once
+        assert plan(32768, 320, K, ks=ks, halo=0) == (T128x320, 1)     # one block spans all of N: A is read from L2 once
     assert plan(32768, 320, 320) == (T128x64w8, 1)            # short K, many rows: small tiles, 4 waves per SIMD
     assert plan(8192, 640, 640) == (T128x64w8, 1)
     assert plan(32768, 960, 320) == (T128x320, 1)             # N > 640: the wide tile
     # 64 tiles of 128x320 would leave 3/4 of the CUs idle
-    assert plan(8192, 640, 5760, ks=3)[0] not in (T128x320, T128x320q, T128x160q)
+    assert plan(8192, 640, 5760, ks=3, halo=0)[0] not in (T128x320, T128x320q, T128x160q)
 
 
 def test_no_split_without_workspace_and_for_geglu():
     assert plan(2048, 1280, 11520, ks=3, ws=False)[1] == 1
+    assert plan(2048, 1280, 11520, ks=3, ws=False, halo=0)[1] == 1
     assert plan(32768, 2560, 320, act=1) == (T128x128w8, 1)    # VD_ACT_GEGLU = 1: 8 waves, value / gate tile pairs
     assert plan(2048, 10240, 1280, act=1) == (T128x128w8, 1)
     assert plan(512, 10240, 1280, act=1) == (T128x128w8, 1)

@@ -367,6 +367,49 @@ def test_conv3x3_concat_rowvec_residual(ops, dev):
     assert rel_l2(out1, ref1) < 2e-3
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, c0, c1, Cout, ups, rowvec, residual
+    (2, 32, 32, 128, 64, 320, 0, True, False),     # two-source concat + per-image row vector (ResBlock conv 1 on a skip concat)
+    (1, 64, 64, 320, 0, 320, 0, False, True),      # residual (ResBlock conv 2); 5 channel chunks
+    (8, 8, 8, 256, 128, 320, 0, True, True),       # four whole 8x8 images per patch
+    (2, 16, 16, 128, 0, 128, 1, False, False),     # nearest-2x upsample in front, 16-wide patches
+    (1, 96, 96, 64, 0, 160, 0, False, True),       # 768^2 latent geometry (96 = 3 patches of 32)
+    (8, 16, 16, 640, 0, 1280, 0, True, False),     # split over channel chunks (fp32 slabs + reduce kernel)
+    (2, 64, 32, 64, 0, 72, 0, False, False),       # N not a multiple of the column tile
+])
+def test_conv3x3_halo_every_variant(ops, dev, case):
+    """conv3x3_halo_kernel: every instantiation (vd_conv_halo_set_variant) and the planner's own choice against torch's fp32
+    convolution; setting 0 runs the same problem on gemm_f16_kernel."""
+    from vd_hip.loader import lib
+    from vd_hip.pack import pack_conv_weight
+    B, H, W, c0, c1, Co, ups, rv, rs = case
+    x = rnd((B, H, W, c0), dev, 1.0, 100)
+    x1 = rnd((B, H, W, c1), dev, 1.0, 101) if c1 else None
+    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.04, 102)
+    b = rnd((Co,), dev, 0.3, 103)
+    Hv, Wv = H << ups, W << ups
+    rowvec = rnd((B, Co), dev, 0.5, 104) if rv else None
+    res = rnd((B, Hv, Wv, Co), dev, 1.0, 105) if rs else None
+    ref = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, ups)
+    if rv:
+        ref = ref + rowvec.float().view(B, 1, 1, Co)
+    if rs:
+        ref = ref + res.float()
+    kw = dict(ksize=3, pad=1, ups=ups, x1=x1)
+    if rv:
+        kw.update(rowvec=rowvec, rows_per_batch=Hv * Wv)
+    if rs:
+        kw.update(res=res)
+    wp = pack_conv_weight(wt)
+    try:
+        for v in [-1] + list(range(0, 9)):
+            assert lib().vd_conv_halo_set_variant(v) == 0
+            out = ops.conv2d_nhwc(x, wp, b, **kw)
+            assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, v
+    finally:
+        lib().vd_conv_halo_set_variant(-1)
+
+
 @pytest.mark.parametrize("B,HW,c0,c1,silu,eps", [(2, 4096, 320, 0, True, 1e-5), (2, 256, 1280, 1280, True, 1e-5),
                                                  (3, 1024, 640, 320, True, 1e-5), (1, 64, 1280, 0, False, 1e-6),
                                                  (1, 16384, 128, 0, True, 1e-6), (2, 4096, 320, 0, False, 1e-6),

@@ -107,9 +107,13 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
     if (setting > 0) {
         v = setting - 1;
     } else {
-        // the planner's choice: 160-column tiles for the UNet's widths (320 / 640 / 1280), 128 for the VAE's
-        if (d.N % 160 == 0) v = 1;
-        else if (d.N % 128 == 0) v = 4;
+        // the planner's choice, measured INSIDE the UNet forward (tools/shape_profile.py under VD_CONV_HALO=k,
+        // tools/halo_forward.py): 256 x 160 blocks of 32 x 160 wave tiles with the pinned request order (MODE 2) win on every
+        // UNet width (320 / 640 / 1280) -- although 64 x 64 wave tiles (256 x 128 blocks) are 5-15 % faster back to back with
+        // warm weights (tools/halo_check.py time), they lose 0.2 ms per forward where weights stream cold; they serve the
+        // widths 160 does not divide (the VAE's 128 / 256 / 512)
+        if (d.N % 160 == 0) v = 2;
+        else if (d.N % 128 == 0) v = 5;
         else return 0;
     }
     const HaloVariant& hv = kHalo[v];
