@@ -128,6 +128,17 @@ int vd_conv_halo_set_variant(int setting);
 int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
 int vd_gemm_tune_clear(void);
 
+/* The gated feed-forward of a BasicTransformerBlock in one launch (inner width C = 320 only: vd_ff_geglu_supported):
+ *     y[m] = res[m] + ( v (*) gelu_erf(g) ) W2^T + b2,     [v | g] = LayerNorm(x[m]) W1^T + b1
+ * x, res, y: fp16 [M][C]; w1_packed: fp16 [8C][C] with LayerNorm's gamma folded in (W1 * gamma) and rows packed per 64 as
+ * [32 value | 32 gate] (VD_ACT_GEGLU layout); b1_packed: fp16 [8C] = beta W1^T + b1, packed likewise; w2: fp16 [C][4C];
+ * b2: fp16 [C].  The rows of x are layer-normalised in registers (biased variance, ln_eps), the [M, 4C] intermediate never
+ * leaves the chip.  Replaces norm3 -> ff (GEGLU -> Linear) -> + x of lib/model_zoo/attention.py:37-64,214-218 and this
+ * library's vd_row_stats_f16 -> vd_gemm_f16(VD_ACT_GEGLU | VD_EPI_LNFOLD) -> vd_gemm_f16(VD_EPI_RESIDUAL) chain. */
+int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void* b1_packed, const void* w2, const void* b2,
+                    const void* res, void* y, int64_t M, int C, float ln_eps, hipStream_t stream);
+int vd_ff_geglu_supported(int C);
+
 /* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
  * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().
  * Replaces GroupNorm32 + SiLU (lib/model_zoo/diffusion_utils.py:175-191, openaimodel.py:196-200,230-237),

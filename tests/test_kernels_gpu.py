@@ -190,6 +190,34 @@ def test_gemm_layernorm_fold_geglu(ops, dev, M, C):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("M,offset", [(128, 0.0), (1000, 0.5), (4096 + 40, -2.0), (32, 8.0)])
+def test_ff_geglu_fused(ops, dev, M, offset):
+    """vd_ff_geglu_f16 (LayerNorm -> GEGLU projection -> gating -> output projection -> + residual in one launch, C = 320)
+    against torch fp32, and against the library's own three-launch chain; rows with a large common offset exercise the
+    in-register LayerNorm (mean >> spread)."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.pack import pack_geglu
+    C = 320
+    assert ops.ff_geglu_supported(C)
+    x = rnd((M, C), dev, 1.2, 80) + offset
+    w1, b1 = rnd((8 * C, C), dev, 0.05, 81), rnd((8 * C,), dev, 0.2, 82)
+    w2, b2 = rnd((C, 4 * C), dev, 0.03, 83), rnd((C,), dev, 0.2, 84)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, device=dev))
+        ln.bias.copy_(0.1 * torch.randn(C, device=dev))
+    xn = F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), 1e-5)
+    v, g = (xn @ w1.float().t() + b1.float()).chunk(2, dim=-1)
+    ref = x.float() + (v * F.gelu(g)) @ w2.float().t() + b2.float()
+    wf, bf, cs = fold_layernorm(w1, b1, ln)
+    wp, bp = pack_geglu(wf, bf)
+    out = ops.ff_geglu(x, wp, bp, w2, b2, x, 1e-5)
+    assert out.shape == x.shape and rel_l2(out, ref) < 3e-3
+    h = ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=wp.float().sum(1).contiguous(), ln_eps=1e-5)
+    chain = ops.linear(h, w2, b2, res=x)
+    assert rel_l2(out, chain.float()) < 3e-3
+
+
 @pytest.mark.parametrize("rows,C,ld", [(1000, 320, 320), (4099, 640, 640), (77, 1280, 1280), (300, 768, 800), (33, 2048, 2048), (5, 64, 64)])
 def test_row_stats(ops, dev, rows, C, ld):
     """vd_row_stats_f16 (statistics of the folded LayerNorm) vs torch fp32, incl. a padded leading dimension, rows that

@@ -30,12 +30,16 @@ class GEGLU(nn.Module, PackCache):
                                   lambda: pack.pack_geglu(_h(self.proj.weight), _h(self.proj.bias)))
             return ops.linear(x, wp, bp, act=ops.ACT_GEGLU)
 
+        wp, bp, cs = self.folded(ln)
+        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=cs, ln_eps=ln.eps)
+
+    def folded(self, ln):
+        """(gamma-folded GEGLU-packed weight, beta-folded packed bias, fp32 row sums of the packed weight), cached."""
         def build():
             w, b, _ = fold_layernorm(_h(self.proj.weight), _h(self.proj.bias), ln)
             wp, bp = pack.pack_geglu(w, b)
             return wp, bp, wp.float().sum(1).contiguous()
-        wp, bp, cs = self._packed("geglu_ln", (self.proj.weight, self.proj.bias, ln.weight, ln.bias), build)
-        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=cs, ln_eps=ln.eps)
+        return self._packed("geglu_ln", (self.proj.weight, self.proj.bias, ln.weight, ln.bias), build)
 
 
 class FeedForward(nn.Module):
@@ -47,7 +51,17 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), Linear(inner, dim_out))
 
     def forward(self, x, res=None, ln=None):
-        return self.net[2](self.net[0](x, ln=ln), res=res)
+        """ln: the LayerNorm in front (folded).  Where the library has the one-launch kernel for this width (C = 320: the
+        64x64 level, whose [M, 4C] GEGLU intermediate is 84 MB) LayerNorm, both projections, the gating and the residual
+        run in vd_ff_geglu_f16; elsewhere GEGLU GEMM -> output GEMM."""
+        C = x.shape[-1]
+        proj, out = self.net[0].proj, self.net[2]
+        if (ln is not None and res is not None and out.bias is not None and proj.bias is not None and proj.in_features == C
+                and out.out_features == C and out.in_features == 4 * C and ops.ff_geglu_supported(C)):
+            wp, bp, _ = self.net[0].folded(ln)
+            w2, b2 = out._w()
+            return ops.ff_geglu(x, wp, bp, w2, b2, res, ln.eps)
+        return out(self.net[0](x, ln=ln), res=res)
 
 
 class CrossAttention(nn.Module, PackCache):

@@ -225,6 +225,31 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     return out
 
 
+FF_FUSED = os.environ.get("VD_FF_FUSED", "1") != "0"   # development switch: 0 = always the three-launch chain
+
+
+def ff_geglu_supported(C):
+    """True when vd_ff_geglu_f16 is instantiated for inner width C (and not switched off)."""
+    return FF_FUSED and bool(lib().vd_ff_geglu_supported(int(C)))
+
+
+def ff_geglu(x, w1_packed, b1_packed, w2, b2, res, ln_eps):
+    """res + (v * gelu(g)) @ w2^T + b2 with [v | g] = LayerNorm(x) @ W1^T + b1 in one launch (vd_ff_geglu_f16);
+    w1_packed / b1_packed: gamma / beta folded, GEGLU-packed (hip_layers.fold_layernorm + pack.pack_geglu)."""
+    for t, n in ((x, "x"), (w1_packed, "w1"), (b1_packed, "b1"), (w2, "w2"), (b2, "b2"), (res, "res")):
+        _req(t, n)
+    C = x.shape[-1]
+    M = x.numel() // C
+    if tuple(w1_packed.shape) != (8 * C, C) or tuple(w2.shape) != (C, 4 * C) or res.shape != x.shape:
+        raise VdHipError("ff_geglu: operand shapes do not match C=%d" % C)
+    y = torch.empty_like(x)
+    flops = 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C
+    with _Timed("ff_geglu_kernel" + ((" M=%d C=%d" % (M, C)) if PROFILE_SHAPES else ""), flops, 2.0 * (3 * M * C + 12 * C * C)):
+        _check(lib().vd_ff_geglu_f16(_ptr(x), _ptr(w1_packed), _ptr(b1_packed), _ptr(w2), _ptr(b2), _ptr(res), _ptr(y), M, C,
+                                     float(ln_eps), _stream()))
+    return y
+
+
 def linear(x, w, bias=None, **kw):
     """x [..., K] @ w[N, K]^T (+bias) -> [..., N]"""
     lead = x.shape[:-1]
