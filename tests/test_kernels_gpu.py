@@ -430,7 +430,7 @@ def test_conv3x3_halo_every_variant(ops, dev, case):
         kw.update(res=res)
     wp = pack_conv_weight(wt)
     try:
-        for v in [-1] + list(range(0, 9)):
+        for v in [-1] + list(range(0, 11)):
             assert lib().vd_conv_halo_set_variant(v) == 0
             out = ops.conv2d_nhwc(x, wp, b, **kw)
             assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, v

@@ -16,6 +16,8 @@ const HaloVariant kHalo[VD_CONV_HALO_VARIANTS] = {
     {256, 128, 512, 2, "conv3x3_halo_kernel<256,128,64,64,512,2>"},
     {256, 160, 256, 1, "conv3x3_halo_kernel<256,160,64,160,256,1>"},
     {256, 160, 256, 2, "conv3x3_halo_kernel<256,160,64,160,256,2>"},
+    {256, 160, 512, 3, "conv3x3_halo_kernel<256,160,32,160,512,3>"},
+    {256, 128, 512, 3, "conv3x3_halo_kernel<256,128,64,64,512,3>"},
 };
 
 std::atomic<int> g_halo_variant{-2};   // -2: not read from the environment yet; -1: planner; 0: off; k > 0: force variant k - 1
@@ -80,6 +82,10 @@ bool halo_geometry(const GemmArgs& a, int BM, ConvHaloArgs& c) {
     c.Wv = Wv;
     c.halo_bytes = ((c.hpx + 7) / 8) * 1024;
     c.g.tiles_m = (int)(d.M / BM);
+    {
+        static const char* abl_env = getenv("VD_HALO_ABL");
+        c.abl = abl_env ? atoi(abl_env) : 0;
+    }
     c.g.d.sync = nullptr;
     return true;
 }
@@ -158,6 +164,8 @@ int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStrea
         case 3: return launch_conv_halo<256, 128, 64, 64, 512, 0>(c, nsplit, stream);
         case 4: return launch_conv_halo<256, 128, 64, 64, 512, 1>(c, nsplit, stream);
         case 5: return launch_conv_halo<256, 128, 64, 64, 512, 2>(c, nsplit, stream);
+        case 8: return launch_conv_halo<256, 160, 32, 160, 512, 3>(c, nsplit, stream);
+        case 9: return launch_conv_halo<256, 128, 64, 64, 512, 3>(c, nsplit, stream);
         default: return vd_conv_halo_launch_big(conv_args, variant, nsplit, stream);
     }
 }

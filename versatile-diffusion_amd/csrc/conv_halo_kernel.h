@@ -50,7 +50,13 @@ struct ConvHaloArgs {
     int nchunks, chunks_per_split;  // 64-channel chunks of the (concatenated) input
     int Hv, Wv;                     // (virtual, i.e. upsampled) image size == output size
     int halo_bytes;                 // one halo buffer: hpx rounded up to whole 8-pixel DMA pieces, x 128
+    int abl;                        // -DVD_HALO_ABLATIONS builds only (timing experiments, wrong results): VD_HALO_ABL
 };
+#ifdef VD_HALO_ABLATIONS
+#define HALO_ABL(p, k) ((p).abl == (k))
+#else
+#define HALO_ABL(p, k) false
+#endif
 
 // MODE 0 / 1 as above.  NT = 64 * waves; wave grid (BM / WM) x (BN / WN), wave tile WM pixels x WN channels.
 template <int BM, int BN, int WM, int WN, int NT, int MODE>
@@ -60,7 +66,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     static_assert(WAVES_M * WAVES_N == NW, "waves must tile the block");
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int WST = MODE == 0 ? 2 : 3;              // weight stages
-    constexpr bool PIN = MODE == 2;                     // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
+    constexpr bool PIN = MODE >= 2;                     // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
+    constexpr bool SPREAD = MODE == 3;                  // MODE 3: MODE 2 with the LDS-DMA requests of a tap issued one per MFMA gap
     constexpr int WSTAGE = BN * 128;                    // bytes of one weight tile [BN][64]
     constexpr int NPW = BN / 8;                         // 1-KiB DMA pieces (8 rows) of a weight tile
     constexpr int WPW = (NPW + NW - 1) / NW;            // ... per wave
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     const int c_begin = split * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > p.nchunks) c_end = p.nchunks;
-    const int ncl = c_end - c_begin;   // >= 1 by construction of the launcher
+    const int ncl = HALO_ABL(p, 2) ? 0 : c_end - c_begin;   // >= 1 by construction of the launcher
 
     struct ChunkSrc { i32x4 rs; int ld2; unsigned soff; };
     auto chunk_src = [&](int c) {   // which tensor / channel offset a 64-channel chunk of the concatenation comes from
@@ -160,8 +167,10 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         s.soff = (unsigned)((second ? cc - d.c0 : cc) * 2);
         return s;
     };
+    bool dma_on = true;
     auto issue_halo = [&](auto jt, const ChunkSrc& cs, unsigned buf_lds) {   // piece j of a chunk -> halo buffer at buf_lds
         constexpr int j = decltype(jt)::value;
+        if (!dma_on) return;
         const int q = j * NW + wave_s;
         if (q * 8 < p.hpx) {   // wave-uniform
             const int h = hsrc[j];
@@ -170,12 +179,20 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         }
     };
     auto issue_w = [&](int c, int tap, int stage) {   // weight tile of (chunk c, tap) -> stage
+        if (!dma_on) return;
         const unsigned soff = (unsigned)((tap * ctot + c * 64) * 2);
 #pragma unroll
         for (int j = 0; j < WPW; ++j) {
             const int q = j * NW + wave_s;
             if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + q * 1024), wvoff[j], soff);
         }
+    };
+
+    auto issue_w_piece = [&](auto jt, int c, int tap, int stage) {   // piece j of the weight tile of (chunk c, tap)
+        constexpr int j = decltype(jt)::value;
+        if (!dma_on) return;
+        const int q = j * NW + wave_s;
+        if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + q * 1024), wvoff[j], (unsigned)((tap * ctot + c * 64) * 2));
     };
 
     // acc[i][j]: TRANSPOSED 32x32 sub-tile (MFMA A operand = weight rows, B operand = pixels): a lane owns output pixel
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         if constexpr (MODE != 0) issue_w(c_begin, 1, 1);
     }
 
+    if (HALO_ABL(p, 3)) dma_on = false;
     if constexpr (MODE == 0) {
         // ---- one barrier at the top of every tap
         for (int lc = 0; lc < ncl; ++lc) {
@@ -324,15 +342,40 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                 wait_vm<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr (t + 2 < 9) issue_w(c, t + 2, (t + 2) % 3);
-                else if (more) issue_w(c + 1, t + 2 - 9, (t + 2) % 3);
-                if constexpr (t < 8) {
-                    if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
+                if constexpr (!SPREAD) {
+                    if constexpr (t + 2 < 9) issue_w(c, t + 2, (t + 2) % 3);
+                    else if (more) issue_w(c + 1, t + 2 - 9, (t + 2) % 3);
+                    if constexpr (t < 8) {
+                        if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
+                    }
+                    read_frags(wst, ta, 3, a1f, w1f);
+                    pin();
+                    mma(a0f, w0f);
+                    pin();
+                } else {
+                    // fragment requests first, then one LDS-DMA piece behind each of the first MFMAs: the matrix pipe runs
+                    // while the request is issued, instead of idling through a burst of WPW + HPT pieces
+                    read_frags(wst, ta, 3, a1f, w1f);
+                    pin();
+                    constexpr int NPIECE = WPW + HPT;
+                    static_for<0, MI * NI>([&](auto mt) {
+                        constexpr int m = decltype(mt)::value;
+                        acc[m / NI][m % NI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0f[m % NI], a0f[m / NI], acc[m / NI][m % NI], 0, 0, 0);
+                        pin();
+                        static_for<0, NPIECE>([&](auto pt) {
+                            constexpr int pc = decltype(pt)::value;
+                            if constexpr (pc * (MI * NI) / NPIECE == m) {   // spread over the MFMAs of this k-step
+                                if constexpr (pc < WPW) {
+                                    if constexpr (t + 2 < 9) issue_w_piece(std::integral_constant<int, pc>{}, c, t + 2, (t + 2) % 3);
+                                    else if (more) issue_w_piece(std::integral_constant<int, pc>{}, c + 1, t + 2 - 9, (t + 2) % 3);
+                                } else if constexpr (t < 8) {
+                                    if (more) issue_halo(std::integral_constant<int, t * HPT + pc - WPW>{}, csn, nxt_halo);
+                                }
+                                pin();
+                            }
+                        });
+                    });
                 }
-                read_frags(wst, ta, 3, a1f, w1f);
-                pin();
-                mma(a0f, w0f);
-                pin();
                 if constexpr (t < 8) {
                     const TapAddr tn_ = tap_addr(halo_off, tapoff_of(t + 1));
                     read_frags(w_smem + ((t + 1) % 3) * WSTAGE, tn_, 0, a0f, w0f);
@@ -398,7 +441,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             const int r = sgm / CH, col = n0 + (sgm % CH) * 8;
             const int row = out_row(r);
             pre[k] = make_uint4(0, 0, 0, 0);
-            if (col < e.N && ld_ok) {
+            if (col < e.N && ld_ok && !HALO_ABL(p, 1)) {
                 if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
                 else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)rv_index(r, row) * e.N + col);
             }
@@ -439,7 +482,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         const int sgm = tid + k * NT;
         const int r = sgm / CH, cc = (sgm % CH) * 8;
         const int col = n0 + cc;
-        if (col < e.N) {
+        if (col < e.N && !(HALO_ABL(p, 1) && r + cc != -1)) {
             const int row = out_row(r);
             U4H8 t, a, b, o;
             t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);

@@ -38,7 +38,7 @@ constexpr int FF_S1 = 16384;              // bytes of a W1 slot (128 rows x 128)
 constexpr int FF_S2 = 20480;              // bytes of a W2 slot (160 rows x 128)
 constexpr int FF_W2 = FF_KT * FF_S1;      // byte offset of the two W2 slots
 constexpr int FF_HT = FF_W2 + 2 * FF_S2;  // ... of the h tile [128][64]
-constexpr int FF_B1 = FF_HT + FF_BM * 128;   // ... of b1 (all 8C packed entries, fp16)
+constexpr int FF_B1 = FF_HT + 2 * FF_BM * 128;   // ... of b1 (all 8C packed entries, fp16); two h tiles (double-buffered)
 constexpr int FF_LDS_MAIN = FF_B1 + 2 * FF_HID * 2;
 constexpr int FF_CS_LD = FF_C + 8;
 constexpr int FF_LDS_EPI = FF_BM * FF_CS_LD * 2;
@@ -58,6 +58,12 @@ struct FFArgs {
     int nt_store;
 };
 
+// VER 0: stage 2 of a chunk right behind its GEGLU epilogue (both waves of a SIMD sit in the VALU-only epilogue at the same
+// time).  VER 1: the epilogue of chunk n shares step C with stage 2 of chunk n - 1 (h tile double-buffered), so its ~350
+// VALU instructions per wave issue in the shadow of 20 MFMAs instead of in front of them.
+// ABL > 0: timing-only ablations (wrong results; VD_FF_ABL): 1 no LDS-DMA in the loop, 2 no GELU arithmetic, 3 no barriers
+// in the loop, 4 no stage-2 MFMAs, 5 no stage-1 MFMAs.
+template <int VER, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void ff_geglu_kernel(const FFArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -89,12 +95,14 @@ __global__ __launch_bounds__(512, 2) void ff_geglu_kernel(const FFArgs p) {
         d2[j] = (unsigned)(__builtin_amdgcn_readfirstlane(q) * 1024);
     }
     auto issue_w1 = [&](int hc, int kt) {   // K tile kt of chunk hc -> slot kt
+        if (ABL == 1 && hc > 0) return;
         const unsigned soff = (unsigned)((hc * 128 * FF_C + kt * 64) * 2);
         const unsigned dst = lds0 + (unsigned)(kt * FF_S1 + wave_s * 1024);
         dma16(rs_w1, dst, v1[0], soff);
         dma16(rs_w1, dst + 8 * 1024, v1[1], soff);
     };
     auto issue_w2 = [&](int hc, int h) {    // rows 160 h .. 160 h + 159 of W2, columns of chunk hc -> slot 5 + h
+        if (ABL == 1 && hc > 0) return;
         const unsigned soff = (unsigned)((h * 160 * FF_HID + hc * 64) * 2);
         const unsigned dst = lds0 + (unsigned)(FF_W2 + h * FF_S2);
 #pragma unroll
@@ -175,73 +183,148 @@ __global__ __launch_bounds__(512, 2) void ff_geglu_kernel(const FFArgs p) {
             U4H8 wv, wg;
             wv.u = *reinterpret_cast<const uint4*>(smem + kt * FF_S1 + rd1[ks]);
             wg.u = *reinterpret_cast<const uint4*>(smem + kt * FF_S1 + rd1[ks] + 32 * 128);
-            acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv.h, xf[kt * 4 + ks], acc1[0], 0, 0, 0);
-            acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg.h, xf[kt * 4 + ks], acc1[1], 0, 0, 0);
+            if constexpr (ABL == 5) {
+                acc1[0][ks] += (float)wv.h[0] * (float)xf[kt * 4 + ks][0];
+                acc1[1][ks] += (float)wg.h[0] * (float)xf[kt * 4 + ks][1];
+            } else {
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv.h, xf[kt * 4 + ks], acc1[0], 0, 0, 0);
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg.h, xf[kt * 4 + ks], acc1[1], 0, 0, 0);
+            }
         }
     };
 
-    for (int hc = 0; hc < FF_NCH; ++hc) {
-        const bool more = hc + 1 < FF_NCH;
-        // ---- step A: K tiles 0, 1 (requested two steps ago; the three tiles requested after them may still be in flight)
-        wait_vm<6>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_w2(hc, 0);
-        issue_w2(hc, 1);
+    auto zero_acc1 = [&]() {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-        stage1_tile(0);
-        stage1_tile(1);
-        // ---- step B: K tiles 2, 3, 4, then value * gelu(gate) -> h tile
-        wait_vm<6>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (more) {
-            issue_w1(hc + 1, 0);
-            issue_w1(hc + 1, 1);
+    };
+    // GEGLU epilogue, group g of chunk hc: 4 consecutive hidden units of this lane's row -> h tile `hb`
+    auto geglu_group = [&](int hc, int g, int hb) {
+        const char* bp = smem + FF_B1 + (hc * 128 + wn * 64 + 4 * hi) * 2;
+        U2H4 bv, bg, o;
+        bv.u = *reinterpret_cast<const uint2*>(bp + 16 * g);
+        bg.u = *reinterpret_cast<const uint2*>(bp + 16 * g + 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = acc1[0][g * 4 + q] + (float)bv.e[q];
+            const float gt = acc1[1][g * 4 + q] + (float)bg.e[q];
+            o.e[q] = ABL == 2 ? (f16)(v + gt) : (f16)(v * vd_gelu_erf(gt));
         }
-        stage1_tile(2);
-        stage1_tile(3);
-        stage1_tile(4);
-        {
-            const char* bp = smem + FF_B1 + (hc * 128 + wn * 64 + 4 * hi) * 2;
+        *reinterpret_cast<uint2*>(smem + wr_h[g] + hb * (FF_BM * 128)) = o.u;
+    };
+    auto stage2_step = [&](int ks, int hb) {
+        U4H8 hf;
+        hf.u = *reinterpret_cast<const uint4*>(smem + rdh[ks] + hb * (FF_BM * 128));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                U2H4 bv, bg, o;
-                bv.u = *reinterpret_cast<const uint2*>(bp + 16 * g);
-                bg.u = *reinterpret_cast<const uint2*>(bp + 16 * g + 64);
+        for (int j = 0; j < 5; ++j) {
+            U4H8 wf;
+            wf.u = *reinterpret_cast<const uint4*>(smem + rd2[ks] + j * 32 * 128);
+            if constexpr (ABL == 4) acc2[j][ks] += (float)wf.h[0] * (float)hf.h[j];
+            else acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, hf.h, acc2[j], 0, 0, 0);
+        }
+    };
+    auto loop_barrier = [&]() { if constexpr (ABL != 3) __builtin_amdgcn_s_barrier(); };
+
+    if constexpr (VER == 0) {
+        for (int hc = 0; hc < FF_NCH; ++hc) {
+            const bool more = hc + 1 < FF_NCH;
+            // ---- step A: K tiles 0, 1 (requested two steps ago; the three tiles requested after them may still be in flight)
+            wait_vm<6>();
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            issue_w2(hc, 0);
+            issue_w2(hc, 1);
+            zero_acc1();
+            stage1_tile(0);
+            stage1_tile(1);
+            // ---- step B: K tiles 2, 3, 4, then value * gelu(gate) -> h tile
+            wait_vm<6>();
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            if (more) {
+                issue_w1(hc + 1, 0);
+                issue_w1(hc + 1, 1);
+            }
+            stage1_tile(2);
+            stage1_tile(3);
+            stage1_tile(4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v = acc1[0][g * 4 + q] + (float)bv.e[q];
-                    const float gt = acc1[1][g * 4 + q] + (float)bg.e[q];
-                    o.e[q] = (f16)(v * vd_gelu_erf(gt));
+            for (int g = 0; g < 4; ++g) geglu_group(hc, g, 0);
+            // ---- step C: out += h W2c^T
+            if (more) wait_vm<4>();
+            else wait_vm<0>();
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            if (more) {
+                issue_w1(hc + 1, 2);
+                issue_w1(hc + 1, 3);
+                issue_w1(hc + 1, 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) stage2_step(ks, 0);
+        }
+    } else {
+        // W2 halves of chunk n are requested at step A of iteration n + 1 and read at its step C (stage 2 runs one chunk late)
+        for (int hc = 0; hc < FF_NCH; ++hc) {
+            const bool first = hc == 0, more = hc + 1 < FF_NCH;
+            // ---- step A: K tiles 0, 1
+            wait_vm<6>();
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            if (!first) {
+                issue_w2(hc - 1, 0);
+                issue_w2(hc - 1, 1);
+            }
+            zero_acc1();
+            stage1_tile(0);
+            stage1_tile(1);
+            // ---- step B: K tiles 2, 3, 4
+            if (first) wait_vm<0>();
+            else wait_vm<6>();
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            if (more) {
+                issue_w1(hc + 1, 0);
+                issue_w1(hc + 1, 1);
+            }
+            stage1_tile(2);
+            stage1_tile(3);
+            stage1_tile(4);
+            // ---- step C: stage 2 of the PREVIOUS chunk with this chunk's GEGLU epilogue in its shadow
+            if (!first) {
+                if (more) wait_vm<4>();
+                else wait_vm<0>();
+            }
+            loop_barrier();
+            asm volatile("" ::: "memory");
+            if (more) {
+                issue_w1(hc + 1, 2);
+                issue_w1(hc + 1, 3);
+                issue_w1(hc + 1, 4);
+            }
+            const int hb = hc & 1;
+            if (!first) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    stage2_step(ks, hb ^ 1);
+                    geglu_group(hc, ks, hb);
                 }
-                *reinterpret_cast<uint2*>(smem + wr_h[g]) = o.u;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) geglu_group(hc, g, hb);
             }
         }
-        // ---- step C: out += h W2c^T
-        if (more) wait_vm<4>();
-        else wait_vm<0>();
+        // ---- tail: stage 2 of the last chunk
+        __builtin_amdgcn_s_barrier();   // every wave has left step C: the W2 slots are free, the last h tile is written
+        asm volatile("" ::: "memory");
+        issue_w2(FF_NCH - 1, 0);
+        issue_w2(FF_NCH - 1, 1);
+        wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (more) {
-            issue_w1(hc + 1, 2);
-            issue_w1(hc + 1, 3);
-            issue_w1(hc + 1, 4);
-        }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            U4H8 hf;
-            hf.u = *reinterpret_cast<const uint4*>(smem + rdh[ks]);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                U4H8 wf;
-                wf.u = *reinterpret_cast<const uint4*>(smem + rd2[ks] + j * 32 * 128);
-                acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, hf.h, acc2[j], 0, 0, 0);
-            }
-        }
+        for (int ks = 0; ks < 4; ++ks) stage2_step(ks, (FF_NCH - 1) & 1);
     }
     wait_vm<0>();
     __syncthreads();   // every wave is done with the slots: the output tile re-uses that LDS
@@ -296,7 +379,15 @@ extern "C" int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void*
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+#ifdef VD_FF_ABLATIONS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_geglu_kernel<0, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+#endif
         if (e != hipSuccess) {
             vd_set_error("vd_ff_geglu_f16: cannot reserve %d bytes of LDS: %s", FF_LDS, hipGetErrorString(e));
             return VD_ERR_LAUNCH;
@@ -308,6 +399,18 @@ extern "C" int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void*
     a.res = (const f16*)res; a.y = (f16*)y; a.M = (int)M; a.eps = ln_eps;
     static const char* nt_env = getenv("VD_GEMM_NT");
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-    hipLaunchKernelGGL(ff_geglu_kernel, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(512), FF_LDS, stream, a);
+    static const char* ver_env = getenv("VD_FF_VER");   // development switch: 0 = epilogue in front of stage 2
+    const dim3 grid((unsigned)((M + FF_BM - 1) / FF_BM));
+#ifdef VD_FF_ABLATIONS
+    static const char* abl_env = getenv("VD_FF_ABL");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    if (abl == 1) { hipLaunchKernelGGL((ff_geglu_kernel<0, 1>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
+    if (abl == 2) { hipLaunchKernelGGL((ff_geglu_kernel<0, 2>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
+    if (abl == 3) { hipLaunchKernelGGL((ff_geglu_kernel<0, 3>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
+    if (abl == 4) { hipLaunchKernelGGL((ff_geglu_kernel<0, 4>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
+    if (abl == 5) { hipLaunchKernelGGL((ff_geglu_kernel<0, 5>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
+#endif
+    if (ver_env && ver_env[0] == '0') hipLaunchKernelGGL(ff_geglu_kernel<0>, grid, dim3(512), FF_LDS, stream, a);
+    else hipLaunchKernelGGL(ff_geglu_kernel<1>, grid, dim3(512), FF_LDS, stream, a);
     return vd_check_launch("vd_ff_geglu_f16");
 }
