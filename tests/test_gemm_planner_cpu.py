@@ -113,3 +113,27 @@ def test_plan_rejects_bad_descriptors():
     cfg, ns = ctypes.c_int(0), ctypes.c_int(0)
     assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) != 0
     assert b"multiple of 8" in lib().vd_last_error()
+
+
+def test_tuned_entry_with_split_is_honoured_on_the_relaunch():
+    """ops.gemm plans first (split_k = 0), then launches with split_k = the planned factor: the second plan must pick the
+    tuned tile again instead of the cost model's tile for that split."""
+    from vd_hip.loader import VdGemmDesc, lib
+    M, N, K = 2048, 1280, 5120
+    try:
+        assert lib().vd_gemm_tune_set(M, N, K, 1, 0, T128x64, 4) == 0
+        for split_k, want in ((0, (T128x64, 4)), (4, (T128x64, 4))):
+            d = VdGemmDesc()
+            d.M, d.N, d.K, d.split_k = M, N, K, split_k
+            d.a0 = d.w = d.out = d.ws = 16
+            cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
+            assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+            assert (cfg.value, ns.value) == want, (split_k, cfg.value, ns.value)
+        d = VdGemmDesc()                      # a different caller-fixed split: the entry does not apply
+        d.M, d.N, d.K, d.split_k = M, N, K, 2
+        d.a0 = d.w = d.out = d.ws = 16
+        cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+        assert ns.value == 2
+    finally:
+        lib().vd_gemm_tune_clear()

@@ -249,11 +249,13 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
             }
     }
     bool tuned = false;
-    if (d.split_k <= 0) {
+    {   // also with a caller-fixed split (ops.gemm plans first, then launches with split_k = the planned factor): the tuned
+        // tile is honoured when its split factor is the one requested
         std::lock_guard<std::mutex> lk(g_tune_mu);
         const int cls = epi_class(d);
         for (const TuneEntry& t : g_tune)
             if (t.M == d.M && t.N == d.N && t.K == d.K && t.ks == d.ksize && t.cls == cls && d.batch == 1) {
+                if (d.split_k > 0 && (t.nsplit > 0 ? t.nsplit : 1) != d.split_k) break;
                 if (t.nsplit > 1 && !can_split) break;
                 if (d.act == VD_ACT_GEGLU && kCfg[t.cfg].bn % 128 != 0) break;
                 cfg = (TileCfg)t.cfg;

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void color_adjust_kernel(const f16* img, const
     const float n = (float)HW;
     const float mi = red[0][0] / n, mr = red[2][0] / n;
     const float vi = fmaxf((red[1][0] - n * mi * mi) / (n - 1.f), 0.f), vr = fmaxf((red[3][0] - n * mr * mr) / (n - 1.f), 0.f);
-    const float scale = sqrtf(vr) / sqrtf(vi), mean_i = mi + ki, mean_r = mr + kr;
+    // a constant output channel (std = 0) has nothing to stretch: it becomes the reference mean (the reference's 0 / 0 is NaN)
+    const float scale = vi > 0.f ? sqrtf(vr) / sqrtf(vi) : 0.f, mean_i = mi + ki, mean_r = mr + kr;
     f16* op = out + ((size_t)b * 3 + c) * HW;
     for (int i = tid; i < HW; i += 256) {
         const float v = ((float)ip[i] - mean_i) * scale + mean_r;

@@ -31,6 +31,12 @@ class DDIMSampler(object):
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
 
+    def release_graphs(self):
+        """Drop the kept step graphs with their static latent / context / K-V buffers and private memory pools (up to two
+        geometries are kept alive per sampler; at 768x768, batch 32 that is a sizeable HBM reservation).  The next
+        sample() call captures again.  Not re-entrant: one sampler serves one request at a time (like the reference's)."""
+        self._static.clear()
+
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
         self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
                                                   num_ddim_timesteps=ddim_num_steps,
@@ -98,6 +104,9 @@ class DDIMSampler(object):
             assert ci["unconditional_guidance_scale"] == scale, \
                 "A different unconditional guidance scale between different context is not allowed!"
         guided = scale != 1.
+        # the loop works on shallow copies: 'c' (the CFG batch, possibly a static buffer the captured graph reads) and
+        # 'kv_cache' never appear in the caller's dicts
+        c_info_list = [dict(ci) for ci in c_info_list]
         # CFG batch [uncond ; cond] assembled ONCE; K/V projections of it cached for the whole loop
         for ci in c_info_list:
             if guided:
@@ -122,8 +131,6 @@ class DDIMSampler(object):
                 if index % log_every_t == 0 or index == total_steps - 1:
                     intermediates["pred_xt"].append(x.to(dtype))
                     intermediates["pred_x0"].append(pred_x0.to(dtype))
-        for ci in c_info_list:
-            ci.pop("kv_cache", None)
         x_info["x"] = x.to(dtype)
         return x_info["x"], intermediates
 
@@ -145,9 +152,10 @@ class DDIMSampler(object):
         projections (refreshed in place by the eager first step of every call)."""
         if not self.graph_cache:
             return None
-        wv = 0
-        for prm in self.model.parameters():   # in-place updates / load_state_dict bump a version, .half() / .to() move storage
-            wv += prm._version + (prm.data_ptr() & 0xFFFFFF)
+        # in-place updates / load_state_dict bump a parameter's version, .half() / .to() move its storage: the key hashes the
+        # ORDERED (storage, version) pairs of every parameter and buffer (an additive checksum would let two parameters
+        # that swap storages collide)
+        wv = hash(tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers())))
         key = (id(self.model), wv, str(x.device), tuple(x.shape), x_info["type"], bool(guided), bool(single),
                tuple((ci["type"], tuple(ci["c"].shape), float(ci.get("ratio", 1.0))) for ci in c_info_list))
         st = self._static.get(key)

@@ -70,14 +70,23 @@ def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_sc
 
     images + fidelity > 0: image variation with fidelity (reference app.py:355-371) -- `images` is THIS RANK's slice of
     the input images [n_local, 3, H, W] in [0, 1]; x0 = vae_encode(images) and only the first int(steps * (1 - fidelity))
-    DDIM steps run (ddim.py:97-103)."""
+    DDIM steps run (ddim.py:97-103).  Posterior and forward-process noise are slices of seeded full-batch draws (see
+    sample_fn), so the result does not depend on the world size."""
     def sample_fn(x_T, ctxs):
         for ci in ctxs:
             ci["unconditional_guidance_scale"] = guidance_scale
         lshape = [x_T.shape[0]] + list(shape[1:])
         if images is not None and fidelity > 0.:
-            x_info = {"type": "image", "x0": net.vae_encode(images, which="image"),
-                      "x0_forward_timesteps": int(steps * (1 - fidelity))}
+            # every random number of this branch comes from a seeded FULL-batch draw sliced to this rank's samples, like
+            # x_T: the forward-process noise of q_sample is the rank's slice of the x_T draw itself (the `x0_noise`
+            # extension of DDIMSampler), the VAE posterior noise a second draw (seed + 1) -- never the rank's own device
+            # generator, so a 1-GPU and an N-GPU run give the same images (and two ranks never repeat each other's noise)
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            lo, hi = shard_bounds(shape[0], world, rank)
+            post = draw_initial_latent(shape, int(seed) + 1)[lo:hi].to(x_T.device)
+            x0 = net.vae_encode(images, which="image", noise=post)
+            x_info = {"type": "image", "x0": x0, "x0_forward_timesteps": int(steps * (1 - fidelity)), "x0_noise": x_T}
         else:
             x_info = {"type": "image", "xt": x_T}
         if len(ctxs) == 1:

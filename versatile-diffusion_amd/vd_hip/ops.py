@@ -547,7 +547,10 @@ def color_adjust(images, ref):
     image for the whole batch) or [B,3,H,W] -> clamp((img - mean) / std * std(ref) + mean(ref), 0, 1) per channel."""
     _req(images, "images"); _req(ref, "ref")
     B, C, H, W = images.shape
-    assert C == 3 and ref.shape[-3:] == (3, H, W)
+    if C != 3 or tuple(ref.shape[-3:]) != (3, H, W) or ref.dim() not in (3, 4) or (ref.dim() == 4 and ref.shape[0] not in (1, B)):
+        raise VdHipError("color_adjust: images [B,3,H,W] = %s need a reference of the same H x W ([3,H,W], [1,3,H,W] or [B,3,H,W]), "
+                         "got %s -- resize the reference to the output size first (app.py:373-379 only uses its per-channel "
+                         "mean / std)" % (tuple(images.shape), tuple(ref.shape)))
     per_image = ref.dim() == 4 and ref.shape[0] == B and B > 1
     out = torch.empty_like(images)
     _check(lib().vd_color_adjust_f16(_ptr(images), _ptr(ref), _ptr(out), B, H, W, 3 * H * W if per_image else 0, _stream()))
