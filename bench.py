@@ -37,6 +37,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_FP16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md chip-level table
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # tools/pmc_traffic.py; stamped with the digest of the library it was taken with
 HBM_PEAK_GBS = 8000.0
 UNET_GF_PER_SAMPLE = 803.3       # 64x64 latent, text ctx L=77
 VAE_DECODE_GF = 2514.5
@@ -156,17 +157,24 @@ def roofline_leg(net, wl, batch, device):
     # applied) over tools/unet_forward.py -- PMC collection cannot run inside this process; null when not collected for
     # this kernel at this round's build
     traffic, traffic_note = None, None
+    alg_bytes = d["mbytes"] * 1e6 / max(d["launches"], 1)   # unique operand bytes per launch (vd_hip/ops.py)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        from vd_hip.loader import lib_digest
+        with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
             pt = json.load(f)
         ent = pt["kernels"].get(dom)
-        if ent and wl["cfg"] == 1:
-            traffic, traffic_note = ent["hbm_side_bytes_per_launch"], "profiles/r02_pmc_traffic.json: " + pt["note"]
-    except Exception:
-        pass
+        if pt.get("library_digest") != lib_digest():
+            traffic_note = "profiles/%s was taken with another build of libvd_hip.so (digest %s, loaded %s): ignored" % (
+                PMC_TRAFFIC_FILE, pt.get("library_digest"), lib_digest())
+        elif ent and wl["cfg"] == 1:
+            traffic = ent["hbm_side_bytes_per_launch"]
+            traffic_note = "profiles/%s (library digest %s): %s" % (PMC_TRAFFIC_FILE, pt["library_digest"], pt["note"])
+    except Exception as e:
+        traffic_note = "no PMC traffic file: %s" % e
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_note": traffic_note,
+            "traffic_note": traffic_note, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "traffic_ratio": (round(traffic / alg_bytes, 2) if traffic else None),
             "launches_per_forward": d["launches"], "avg_launch_us": round(d["avg_us"], 1),
             "algorithmic_gflop_per_launch": round(d["gflop"] / max(d["launches"], 1), 2),
             "forward_ms_instrumented": round(sum(v["ms"] for v in table.values()), 3),
@@ -238,6 +246,8 @@ def cpu_baseline_leg(net, device):
     torch.set_num_threads(prev)
     per_image = 50 * t_fwd + t_dec
     return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "kind_note": "CPU fp32 restatement of the reference's path (oracle/, pinned to the reference by fixtures and live "
+                         "differentials); the reference tree itself is absent on the GPU box",
             "sample": "oracle fp32 on %d pinned threads: 1 UNet forward (CFG batch 2, 64x64x4 latent, L=77) = %.2f s; 1 VAE "
                       "decode 32x32 latent x4 area = %.2f s; extrapolated 50*forward + decode per image" % (cores, t_fwd, t_dec)}
 

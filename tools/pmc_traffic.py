@@ -10,6 +10,11 @@ import collections, json, re, sqlite3, sys
 
 
 def norm(name):
+    m = re.search(r"(conv3x3_halo_kernel)<([^>]*)>", name)
+    if m:
+        return "%s<%s>" % (m.group(1), ",".join(a.strip() for a in m.group(2).split(",")))
+    if "ff_geglu_kernel" in name:
+        return "ff_geglu_kernel"
     m = re.search(r"(gemm_f16_kernel|attn_fwd_kernel)<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
@@ -35,8 +40,13 @@ def collect(path, counter):
     return acc
 
 
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "versatile-diffusion_amd"))
+from vd_hip.loader import lib_digest
+
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python tools/unet_forward.py 3",
+out = {"library_digest": lib_digest(),   # of the libvd_hip.so the passes ran with: bench.py ignores the file when it differs
+       "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python tools/unet_forward.py 3",
        "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 rocprofv3 reports half of a wide coalesced read "
                "(MI355X_MICROARCH.md, HBM section); counters sit on the L2's fabric side, so Infinity-Cache hits are "
                "included (upper bound on HBM bytes); WRITE_SIZE uncalibrated",

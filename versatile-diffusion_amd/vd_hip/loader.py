@@ -84,6 +84,17 @@ def lib_path():
     return _LIB_PATH
 
 
+def lib_digest():
+    """First 16 hex digits of the SHA-256 of the library file that is (or would be) loaded: stamps measurements that depend on
+    the exact kernels (profiles/rNN_pmc_traffic.json) so bench.py can tell a stale file from a current one."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(_LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def available():
     return os.path.exists(_LIB_PATH)
 

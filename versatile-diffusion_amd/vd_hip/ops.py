@@ -220,7 +220,14 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             cls = (1 if act == ACT_GEGLU else 0) | (2 if colsum is not None else 0) | (4 if a1 is not None else 0)
             name += " M=%d N=%d K=%d ks=%d cls=%d split=%d" % (M, N, K, max(int(d.ksize), 1), cls, plan_ns.value)
     nb = max(batch, 1)
-    with _Timed(name, 2.0 * nb * M * N * K, 2.0 * nb * (M * K + N * K + M * n_out)):
+    # algorithmic bytes = every operand ONCE: a convolution reads its input pixels (B * Hin * Win * (c0 + c1)), not the
+    # M x K im2col matrix (9x that for a 3x3)
+    if conv is not None:
+        a_elems = float(conv["B"]) * conv["Hin"] * conv["Win"] * (d.c0 + d.c1)
+    else:
+        a_elems = float(M) * K
+    extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
+    with _Timed(name, 2.0 * nb * M * N * K, 2.0 * (nb * (a_elems + float(N) * K + float(M) * n_out) + extra)):
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
     return out
 
