@@ -399,8 +399,76 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         return ((img0 + grp) * p.Hv + y0 + (r >> p.ltw)) * p.Wv + x0 + (r & (p.tw - 1));
     };
 
-    // ---- split-K: fp32 slabs for splitk_reduce_kernel, straight from registers
-    if (gridDim.y > 1) {
+    // ---- split-K with tickets (d.sync: two zeroed counters per tile, re-armed here): the blocks of a tile draw a ticket when
+    // their chunks are done.  Tickets 0 .. nsplit - 2 leave their fp32 accumulators in the workspace in REGISTER order
+    // ([8-byte group][thread]: coalesced, no index arithmetic) and bump the tile's `done` counter; the block with the LAST
+    // ticket keeps its accumulators in registers, waits until the others have published (they hold tickets, so they are
+    // running: the wait cannot deadlock), adds their slabs in ticket order and carries on into the fused epilogue.  One
+    // slab less is written and read than with the reduce kernel, no second launch, no fp32 round trip of the last partial.
+    // Coherence (XCD L2s are not coherent): slab stores and loads are agent-scope relaxed atomics (sc1: write-through /
+    // L1 bypass), ordered against the counters by s_waitcnt vmcnt(0) + the workgroup barrier (MI355X guide, R1 form).
+    if (gridDim.y > 1 && d.sync != nullptr) {
+        typedef unsigned long long u64;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int G2 = MI * NI * 8;   // 8-byte groups per thread
+        const int nsplit = gridDim.y;
+        const int tile_id = tm * p.g.tiles_n + tn;
+        int* ticket_ctr = d.sync + 2 * tile_id;
+        int* done_ctr = ticket_ctr + 1;
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *flag;
+        u64* slab0 = reinterpret_cast<u64*>(d.ws) + (size_t)tile_id * (nsplit - 1) * (size_t)(G2 * NT);
+        if (ticket < nsplit - 1) {
+            u64* mine = slab0 + (size_t)ticket * (G2 * NT) + tid;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        __hip_atomic_store(mine + ((i * NI + j) * 8 + g) * NT,
+                                           __builtin_bit_cast(u64, f32x2{acc[i][j][g * 2], acc[i][j][g * 2 + 1]}),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are acknowledged at device scope
+            __syncthreads();                                   // ... and every wave's
+            if (tid == 0) __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 24)) break;   // never seen; a bounded wait cannot hang the device
+            }
+            __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const u64* src = slab0 + tid;
+        for (int s = 0; s < nsplit - 1; ++s, src += G2 * NT) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    u64 v[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        v[g] = __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const f32x2 f = __builtin_bit_cast(f32x2, v[g]);
+                        acc[i][j][g * 2] += f.x;
+                        acc[i][j][g * 2 + 1] += f.y;
+                    }
+                }
+        }
+        __syncthreads();   // the ticket word in LDS has been read by everyone: the epilogue tile may overwrite it
+    }
+
+    // ---- split-K without counters: fp32 slabs for splitk_reduce_kernel, straight from registers
+    if (gridDim.y > 1 && d.sync == nullptr) {
         float* base = d.ws + (size_t)split * (size_t)d.M * d.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {

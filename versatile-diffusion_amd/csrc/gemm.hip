@@ -393,9 +393,10 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
     if (cfg >= T_COUNT) {   // halo-resident 3x3 convolution; split-K slabs go through the same reduce kernel
         halo.g.nt_store = a.nt_store;
+        if (nsplit <= 1 || 2l * halo.g.tiles_m * halo.g.tiles_n > VD_GEMM_SYNC_INTS) halo.g.d.sync = nullptr;
         rc = vd_conv_halo_launch(&halo, cfg - T_COUNT, nsplit, stream);
         if (rc != VD_OK) return rc;
-        if (nsplit > 1) {
+        if (nsplit > 1 && halo.g.d.sync == nullptr) {   // no ticket counters: slabs + the reduce kernel
             a.d.sync = nullptr;
             const size_t total = (size_t)d.M * ((d.N + 7) / 8);
             int blocks = (int)((total + 255) / 256);

@@ -106,6 +106,7 @@ def workspace(nbytes, device, tag="ws"):
 
 SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
 FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
+HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "1") != "0"   # development switch: 0 = slabs + reduce kernel for the halo conv too
 
 
 def sync_counters(device):
@@ -211,7 +212,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         d.ws = None
         if plan_ns.value > 1:
             d.split_k = plan_ns.value
-            d.sync = sync_counters(a0.device).data_ptr() if (FIXUP_DEFAULT if fixup is None else fixup) else None
+            # the halo conv kernel reduces its channel-chunk split in-kernel through ticket counters (conv_halo_kernel.h);
+            # gemm_f16_kernel's own last-arriver fix-up stays opt-in
+            halo = plan_cfg.value >= lib().vd_gemm_num_configs()
+            use_sync = HALO_FIXUP if halo else (FIXUP_DEFAULT if fixup is None else fixup)
+            d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
