@@ -69,5 +69,5 @@ def test_header_compiles_as_plain_c_and_layout_matches_ctypes(tmp_path):
     for field, key in (("M", "off_M"), ("stride_a", "off_stride_a"), ("colsum", "off_colsum"), ("sync", "off_sync"), ("ln_stats", "off_ln_stats")):
         assert int(kv[key]) == getattr(VdGemmDesc, field).offset, field
     # same plan as the ctypes path (tests/test_gemm_planner_cpu.py): the 16x16-level 3x3 conv runs on the halo kernel, 4-way split
-    assert lines[1].startswith("plan rc=0 cfg=27 ns=4 name=conv3x3_halo_kernel<256,160,32,160,512,2>")
+    assert lines[1].startswith("plan rc=0 cfg=29 ns=4 name=conv3x3_halo_kernel<256,160,32,160,512,2>")
     assert "bad rc=-" in lines[2] and "multiple of 8" in lines[2]

@@ -13,7 +13,7 @@ T128x128, T128x64, T64x64, T128x128w8, T128x320 = 0, 1, 2, 3, 7
 T128x64d, T64x64d = 14, 15                                   # 3-stage ring for grids that do not fill the chip
 T128x128q, T128x128w8q, T128x320q, T128x160q = 16, 19, 20, 21   # 32-deep K tiles, 4-stage ring: VD_GEMM_VARIANT=q|h only
 T128x64w8, T256x256 = 4, 24
-NCFG = 25                                                    # vd_gemm_num_configs(): classic gemm_f16_kernel instantiations
+NCFG = 27                                                    # vd_gemm_num_configs(): classic gemm_f16_kernel instantiations
 H160p, H128p = NCFG + 2, NCFG + 5                            # conv3x3_halo_kernel<256,160,...,2> / <256,128,...,2>
 
 

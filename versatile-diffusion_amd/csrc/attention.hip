@@ -14,6 +14,7 @@
 //   transposed while it is staged (LDS holds V^T[d][key]) so the A operand is two ds_read_b64.
 //   O^T accumulators: lane owns its query column again, so rescaling by exp(m_old - m_new) is
 //   lane-local as well.
+#include <stdlib.h>
 #include <type_traits>
 #include "vd_common.h"
 #include "../../include/vd_hip.h"
@@ -37,6 +38,7 @@ struct AttnArgs {
     float scale_log2;
     int causal;
     int nqb, BH;
+    int ctx_map;   // block -> (batch, head, query block) mapping for short contexts, see the kernel
 };
 
 template <int D>
@@ -64,7 +66,16 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     int qb, bh;
     {
         const int bid = blockIdx.x;
-        if ((p.BH & 7) == 0) {
+        if (p.ctx_map) {
+            // short context (cross-attention, Nk of one or two tiles): K / V re-use across query blocks is worthless, what
+            // costs is that the H heads of a query row each touch D * 2 bytes of the same cache lines of q and out.  Run the
+            // heads of one (batch, query block) back to back on ONE XCD: the partial-line stores merge in its L2 and q
+            // lines are fetched once.  (The number of (batch, query block) groups must be a multiple of 8.)
+            const int xcd = bid & 7, idx = bid >> 3;
+            const int grp = xcd + 8 * (idx / p.H);
+            bh = (grp / p.nqb) * p.H + idx % p.H;
+            qb = grp % p.nqb;
+        } else if ((p.BH & 7) == 0) {
             const int xcd = bid & 7, idx = bid >> 3;
             bh = xcd + 8 * (idx / p.nqb);
             qb = idx % p.nqb;
@@ -376,6 +387,8 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     a.causal = causal;
     a.nqb = (Nq + QB - 1) / QB;
     a.BH = B * H;
+    static const char* ctx_env = getenv("VD_ATTN_CTXMAP");   // development switch: 0 = always the K/V-locality mapping
+    a.ctx_map = (Nk <= 2 * KV && ((B * a.nqb) & 7) == 0 && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
     switch (D) {
         case 40: return launch_attn<40>(a, stream);
         case 64: return launch_attn<64>(a, stream);

@@ -78,7 +78,9 @@ enum TileCfg {
     // 32-deep K tiles, 4-stage ring (same LDS footprint as 64-deep / 2 stages, tiles issued 3 ahead instead of 1)
     T128x128q = 16, T128x64q = 17, T64x64q = 18, T128x128w8q = 19, T128x320q = 20, T128x160q = 21,
     T256x320 = 22, T256x320q = 23, T256x256 = 24,
-    T_COUNT = 25
+    // 3 stages, mid-barrier main loop with pinned one-k-step-ahead fragment requests (gemm_kernel.h: MID)
+    T256x128m = 25, T128x128m = 26,
+    T_COUNT = 27
 };
 struct CfgInfo { int bm, bn; const char* name; };
 const CfgInfo kCfg[T_COUNT] = {
@@ -94,7 +96,8 @@ const CfgInfo kCfg[T_COUNT] = {
     {64, 64, "gemm_f16_kernel<64,64,32,32,256,4,32>"},       {128, 128, "gemm_f16_kernel<128,128,32,64,512,4,32>"},
     {128, 320, "gemm_f16_kernel<128,320,32,160,512,4,32>"},  {128, 160, "gemm_f16_kernel<128,160,32,160,256,4,32>"},
     {256, 320, "gemm_f16_kernel<256,320,64,160,512,2,64>"},  {256, 320, "gemm_f16_kernel<256,320,64,160,512,4,32>"},
-    {256, 256, "gemm_f16_kernel<256,256,64,128,512,2,64>"}};
+    {256, 256, "gemm_f16_kernel<256,256,64,128,512,2,64>"},
+    {256, 128, "gemm_f16_kernel<256,128,64,64,512,3,64>"},   {128, 128, "gemm_f16_kernel<128,128,32,64,512,3,64>"}};
 
 std::atomic<int> g_override{-1};
 
@@ -269,7 +272,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         int ov = g_override.load(std::memory_order_relaxed);
         if (ov < 0 && ov_env) ov = atoi(ov_env);
         const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T256x128 || ov == T128x256 || ov == T128x256b || ov == T128x128d ||
-                              ov == T128x128q || ov == T128x128w8q || ov == T256x256;
+                              ov == T128x128q || ov == T128x128w8q || ov == T256x256 || ov == T256x128m || ov == T128x128m;
         if (ov >= 0 && ov < T_COUNT && (d.act != VD_ACT_GEGLU || geglu_ok) && !(d.M < 96 || d.N < 96)) {
             cfg = (TileCfg)ov;
             // re-plan the split for the forced tile: fill the chip once (one block per CU for the 1-block-per-CU tiles)
@@ -318,7 +321,8 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     if (lnfold) {
         // the LayerNorm fold is a compile-time variant of the kernel, instantiated for these tiles only
         switch (cfg) {
-            case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T64x64d: case T256x256: break;
+            case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T64x64d: case T256x256:
+            case T256x128m: case T128x128m: break;
             case T128x64d: case T128x64q: cfg = T128x64; break;
             case T64x64q: cfg = T64x64; break;
             case T128x128q: case T128x128d: cfg = T128x128; break;
@@ -416,6 +420,8 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
             case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512, 2, 64, 4, true>(a, nsplit, stream); break;
             case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512, 2, 64, 4, true>(a, nsplit, stream); break;
             case T128x320: rc = launch_cfg<128, 320, 32, 160, 512, 2, 64, 2, true>(a, nsplit, stream); break;
+            case T256x128m: rc = launch_cfg<256, 128, 64, 64, 512, 3, 64, 2, true, true>(a, nsplit, stream); break;
+            case T128x128m: rc = launch_cfg<128, 128, 32, 64, 512, 3, 64, 2, true, true>(a, nsplit, stream); break;
             default: rc = vd_gemm_launch_big(cfg, 1, &a, nsplit, stream); break;   // 256x256 (GEGLU)
         }
         return rc;
@@ -439,6 +445,8 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         case T128x128w8q: rc = launch_cfg<128, 128, 32, 64, 512, 4, 32, 4>(a, nsplit, stream); break;
         case T128x320q: rc = launch_cfg<128, 320, 32, 160, 512, 4, 32, 2>(a, nsplit, stream); break;
         case T128x160q: rc = launch_cfg<128, 160, 32, 160, 256, 4, 32, 2>(a, nsplit, stream); break;
+        case T256x128m: rc = launch_cfg<256, 128, 64, 64, 512, 3, 64, 2, false, true>(a, nsplit, stream); break;
+        case T128x128m: rc = launch_cfg<128, 128, 32, 64, 512, 3, 64, 2, false, true>(a, nsplit, stream); break;
         default: rc = vd_gemm_launch_big(cfg, 0, &a, nsplit, stream); break;
     }
     if (rc != VD_OK) return rc;

@@ -236,8 +236,12 @@ __device__ __forceinline__ void wait_vm() {
 template <int BM, int BN, int NT, int STAGES, int KB>
 constexpr int gemm_lds_bytes();   // stages / epilogue tile (defined with the launcher below)
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
+// MID (3 stages, 64-deep tiles only): the main loop of conv3x3_halo_kernel's MODE 2 -- the barrier of a K tile sits BEHIND
+// its first two k-steps, tiles are requested two ahead, operand fragments one k-step ahead in two named register sets with
+// the request / MFMA order pinned: nothing a wave needs right after the barrier depends on it.
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false, bool MID = false>
 __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
+    static_assert(!MID || (STAGES == 3 && KB == 64), "the mid-barrier loop walks 64-deep tiles through three stages");
     // wave tiles of 8+ MFMA tiles at two waves per SIMD (256 registers each) cannot hold two fragment sets next to the
     // accumulators: those instances read the fragments of a k-step right before its MFMAs (the partner wave covers the wait)
     constexpr int FB = ((WM / 32) * (WN / 32) >= 8 && OCC >= 2) ? 1 : 2;
@@ -527,6 +531,56 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         }  // FB == 2
     };
 
+    if constexpr (MID) {
+        if (nk > 0) {
+            auto issue_tile = [&](int t, int buf) {
+                issue_begin(kt0 + t, buf);
+#pragma unroll
+                for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
+            };
+            auto mma = [&](const f16x8* a, const f16x8* b) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NI; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nj], a[mi], acc[mi][nj], 0, 0, 0);
+            };
+            auto pin = []() { __builtin_amdgcn_sched_barrier(0); };
+            issue_tile(0, 0);
+            if (nk > 1) issue_tile(1, 1);
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            f16x8 a0f[MI], b0f[NI], a1f[MI], b1f[NI];
+            read_frags(smem, 0, a0f, b0f);
+            int cb = 0;
+            for (int i = 0; i < nk; ++i) {
+                const int nb = cb == 2 ? 0 : cb + 1, ib = nb == 2 ? 0 : nb + 1;
+                const char* st = smem + cb * STAGE_BYTES;
+                read_frags(st, 1, a1f, b1f);
+                pin();
+                mma(a0f, b0f);
+                pin();
+                read_frags(st, 2, a0f, b0f);
+                pin();
+                mma(a1f, b1f);
+                // tile i + 1 (requested one tile ago) has landed for every wave; every wave has left tile i - 1, whose
+                // stage the request below overwrites
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (i + 2 < nk) issue_tile(i + 2, ib);
+                read_frags(st, 3, a1f, b1f);
+                pin();
+                mma(a0f, b0f);
+                pin();
+                if (i + 1 < nk) read_frags(smem + nb * STAGE_BYTES, 0, a0f, b0f);
+                pin();
+                mma(a1f, b1f);
+                cb = nb;
+            }
+        }
+    } else {
 #ifndef VD_GEMM_PIPELINED
     // ---- main loop (default): every K tile = { wait for the tile, barrier, issue the tile D ahead as ONE burst, then the
     // compiler-scheduled ds_read / MFMA stream of the landed tile }.  The burst gives a DMA the longest possible lead (a
@@ -599,6 +653,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         iteration(std::integral_constant<int, 2>{}, i, cbuf, 0, 0);
     }
 #endif
+    }   // !MID
+    wait_vm<0>();
     __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
 
     const EpiCtx e = make_epi(d, z);
@@ -835,7 +891,7 @@ constexpr int gemm_lds_bytes() {
     return stage > epi ? stage : epi;
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false>
+template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false, bool MID = false>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>() + (LNF ? BN * 4 : 0);   // + the block's colsum entries
     static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
@@ -845,7 +901,7 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF, MID>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             vd_set_error("vd_gemm_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -854,7 +910,7 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
         done.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.d.batch > 0 ? a.d.batch : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF>), grid, dim3(NT), LDS, stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, NT, STAGES, KB, OCC, LNF, MID>), grid, dim3(NT), LDS, stream, a);
     return vd_check_launch("vd_gemm_f16");
 }
 
