@@ -429,12 +429,18 @@ def test_conv3x3_halo_every_variant(ops, dev, case):
     if rs:
         kw.update(res=res)
     wp = pack_conv_weight(wt)
+    keep = ops.HALO_FIXUP
     try:
-        for v in [-1] + list(range(0, 11)):
-            assert lib().vd_conv_halo_set_variant(v) == 0
-            out = ops.conv2d_nhwc(x, wp, b, **kw)
-            assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, v
+        for fixup in (False, True):      # channel-chunk split: slabs + reduce kernel / ticketed in-kernel reduction
+            ops.HALO_FIXUP = fixup
+            for v in [-1] + list(range(0, 11)):
+                assert lib().vd_conv_halo_set_variant(v) == 0
+                out = ops.conv2d_nhwc(x, wp, b, **kw)
+                assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, (v, fixup)
+            for rep in range(3):          # the counters re-arm: repeated launches stay correct
+                assert rel_l2(ops.conv2d_nhwc(x, wp, b, **kw), ref) < 2e-3, (rep, fixup)
     finally:
+        ops.HALO_FIXUP = keep
         lib().vd_conv_halo_set_variant(-1)
 
 

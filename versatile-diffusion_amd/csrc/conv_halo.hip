@@ -86,7 +86,6 @@ bool halo_geometry(const GemmArgs& a, int BM, ConvHaloArgs& c) {
         static const char* abl_env = getenv("VD_HALO_ABL");
         c.abl = abl_env ? atoi(abl_env) : 0;
     }
-    c.g.d.sync = nullptr;
     return true;
 }
 

@@ -106,7 +106,9 @@ def workspace(nbytes, device, tag="ws"):
 
 SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
 FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
-HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "1") != "0"   # development switch: 0 = slabs + reduce kernel for the halo conv too
+# opt-in (VD_HALO_FIXUP=1): the halo conv reduces its channel-chunk split in-kernel through ticket counters instead of the
+# reduce launch.  Correct, not faster: equal at a 2-way split, 9 us slower per conv at 4-way, forward 11.98 vs 11.93 ms.
+HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"
 
 
 def sync_counters(device):
@@ -212,8 +214,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         d.ws = None
         if plan_ns.value > 1:
             d.split_k = plan_ns.value
-            # the halo conv kernel reduces its channel-chunk split in-kernel through ticket counters (conv_halo_kernel.h);
-            # gemm_f16_kernel's own last-arriver fix-up stays opt-in
+            # in-kernel reductions (ticket counters of the halo conv, conv_halo_kernel.h; last-arriver fix-up of
+            # gemm_f16_kernel) are opt-in: the reduce launch measured faster for both
             halo = plan_cfg.value >= lib().vd_gemm_num_configs()
             use_sync = HALO_FIXUP if halo else (FIXUP_DEFAULT if fixup is None else fixup)
             d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
