@@ -97,7 +97,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.g.tiles_n, tn = bid - tm * p.g.tiles_n;
+    const int tm = p.g.mfast ? bid % p.g.tiles_m : bid / p.g.tiles_n;   // see gemm_f16_kernel: which operand an XCD keeps
+    const int tn = p.g.mfast ? bid / p.g.tiles_m : bid - tm * p.g.tiles_n;
     const int n0 = tn * BN;
     const int split = blockIdx.y;
 

@@ -395,6 +395,20 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    {   // which operand an XCD keeps in its private L2 (see the tile mapping in gemm_kernel.h): fabric bytes of the two orders
+        static const char* mf_env = getenv("VD_GEMM_MFAST");   // development switch: 0 = always n fastest, 1 = always m fastest
+        const int tiles_m = cfg >= T_COUNT ? halo.g.tiles_m : a.tiles_m, tiles_n = cfg >= T_COUNT ? halo.g.tiles_n : a.tiles_n;
+        const double wbytes = (double)d.N * d.K * 2.0, abytes = (double)a.a0_bytes + a.a1_bytes;
+        const double runs = (double)tiles_m * tiles_n / 8.0;   // tiles per XCD
+        // n fastest: an XCD covers min(tiles_n, runs) column panels and runs / tiles_n (>= 1) row panels
+        const double nfast = 8.0 * wbytes * (runs < tiles_n ? runs / tiles_n : 1.0) + abytes * (runs < tiles_n ? tiles_n / runs : 1.0);
+        const double mfast = 8.0 * abytes * (runs < tiles_m ? runs / tiles_m : 1.0) + wbytes * (runs < tiles_m ? tiles_m / runs : 1.0);
+        static const char* thr_env = getenv("VD_GEMM_MFAST_THR");
+        static const double thr = thr_env ? atof(thr_env) : 0.8;
+        a.mfast = (zb == 1 && mfast < thr * nfast) ? 1 : 0;
+        if (mf_env) a.mfast = (mf_env[0] == '1' && zb == 1) ? 1 : 0;
+        halo.g.mfast = a.mfast;
+    }
     if (cfg >= T_COUNT) {   // halo-resident 3x3 convolution; split-K slabs go through the same reduce kernel
         halo.g.nt_store = a.nt_store;
         if (nsplit <= 1 || 2l * halo.g.tiles_m * halo.g.tiles_n > VD_GEMM_SYNC_INTS) halo.g.d.sync = nullptr;

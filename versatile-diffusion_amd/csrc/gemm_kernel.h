@@ -48,6 +48,7 @@ struct GemmArgs {
     unsigned a0_bytes, a1_bytes, w_bytes;  // per-batch operand extents for the buffer descriptors (< 2^31)
     int plain;                             // 1x1, stride 1, no pad / upsample, output grid == input grid
     int nt_store;                          // non-temporal output stores (streaming results that nobody re-reads soon)
+    int mfast;                             // XCD tile runs walk m fastest (tiles of one weight column panel share an L2)
 };
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
@@ -283,15 +284,18 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int hi = lane >> 5, l31 = lane & 31;
 
-    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of
-    // logical tiles (n fastest) so neighbouring tiles that share the A row-panel share an L2.
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of logical tiles.  n fastest:
+    // neighbouring tiles share the A row-panel in that XCD's L2 and every XCD streams ALL of W through the fabric (8 x W).
+    // m fastest (p.mfast, chosen by the host where 8 x W outweighs tiles_n x A: the weight-heavy 16x16 / 32x32 levels): an
+    // XCD owns a few weight column panels and re-reads the (small) activation instead.
     const int ntiles = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+    const int tm = p.mfast ? bid % p.tiles_m : bid / p.tiles_n;
+    const int tn = p.mfast ? bid / p.tiles_m : bid - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int z = blockIdx.z;
