@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 2
+#define VD_HIP_ABI_VERSION 3
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */

@@ -521,6 +521,20 @@ def test_attention(ops, dev, B, H, Nq, Nk, D, causal):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("B,N,D", [(2, 1024, 512), (1, 4096, 512), (1, 1000, 512), (2, 333, 256), (3, 64, 128)])
+def test_attention_one_wide_head(ops, dev, B, N, D):
+    """vd_attention_f16 with one head of 128 / 256 / 512 channels (AutoencoderKL mid-block AttnBlock): head dim split over the
+    four waves of a block, partial scores exchanged through LDS; ragged key / query counts; q / k / v as column slices of a
+    fused projection; one spiked key forces the deferred rescale."""
+    qkv = rnd((B, N, 3 * D), dev, 0.6, 90)
+    qkv[:, N // 2, D:2 * D] *= 6.0
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    scale = D ** -0.5
+    ref = torch.softmax((q.float() @ k.float().transpose(1, 2)) * scale, dim=-1) @ v.float()
+    out = ops.attention(q, k, v, 1, scale=scale)
+    assert out.shape == (B, N, D) and rel_l2(out, ref) < 3e-3
+
+
 def test_attention_fused_qkv_views_and_spike(ops, dev):
     """Strided column views of one fused projection; a spiked key forces a late running-max jump."""
     B, N, H, D = 2, 512, 8, 40

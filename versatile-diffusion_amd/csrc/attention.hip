@@ -14,6 +14,7 @@
 //   transposed while it is staged (LDS holds V^T[d][key]) so the A operand is two ds_read_b64.
 //   O^T accumulators: lane owns its query column again, so rescaling by exp(m_old - m_new) is
 //   lane-local as well.
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include "vd_common.h"
@@ -339,6 +340,205 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     }
 }
 
+// ---- single-head attention over a WIDE head (D = 128 / 256 / 512): the AutoencoderKL mid-block AttnBlock
+// (/root/reference/lib/model_zoo/autokl_modules.py:150-202: q, k, v 1x1 convs over C = 512 channels, torch.bmm -> softmax ->
+// torch.bmm; 4096 tokens at 512x512, 9216 at 768x768).  The O accumulator of a 32-query block is 32 x 512 fp32 -- too wide for
+// one wave -- so the head dim is SPLIT OVER THE FOUR WAVES of a block: wave w owns d in [w D/4, (w + 1) D/4).  Per tile of 32
+// keys every wave computes the partial S^T = K[:, slice] Q^T[slice] of its slice, the four partials meet in LDS (one
+// exchange, double-buffered), every wave then holds the full score tile, runs the same online softmax (fp32 statistics,
+// deferred rescale) and accumulates O^T[slice] += V^T[slice] P^T.  No [N, N] tensor exists anywhere.
+//   LDS per stage: K image [32 keys][D] (16-byte slots XOR-ed with key & 15 on the DMA source side: conflict-free
+//   ds_read_b128 of 32 key rows), V image [D / 32 panels][32 keys][32] read transposed (ds_read_b64_tr_b16) like above;
+//   two stages + two exchange buffers = 160 KiB at D = 512.
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_wide_kernel(const AttnArgs p) {
+    constexpr int KVW = 32;                 // keys per tile
+    constexpr int DW = D / 4;               // head-dim slice of a wave
+    constexpr int KSW = DW / 16;            // k-steps of the partial QK^T
+    constexpr int DBW = DW / 32;            // 32-row blocks of O^T per wave == V panels per wave
+    constexpr int SPR = D / 8;              // 16-byte slots per K row
+    constexpr int K_BYTES = KVW * D * 2;
+    constexpr int V_BYTES = KVW * D * 2;
+    constexpr int TILE_BYTES = K_BYTES + V_BYTES;
+    constexpr int XCH_BYTES = 4 * 64 * 16 * 4;   // four partial score tiles: [wave][4 groups][64 lanes] float4
+    constexpr int NPIECE = K_BYTES / 1024;       // DMA pieces per operand and tile
+    constexpr int PPW = NPIECE / 4;              // ... per wave
+    static_assert(D % 128 == 0 && D <= 512 && SPR >= 16 && NPIECE % 4 == 0, "head dim");
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];   // [2 stages][K | V] then [2][exchange]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / p.nqb, qb = blockIdx.x % p.nqb;
+    const f16* qp = p.q + (size_t)b * p.sq;
+    const f16* kp = p.k + (size_t)b * p.sk;
+    const f16* vp = p.v + (size_t)b * p.sv;
+    f16* op = p.o + (size_t)b * p.so;
+    const i32x4 rs_k = make_rsrc_words(kp, (unsigned)(((size_t)(p.Nk - 1) * p.ldk + D) * 2));
+    const i32x4 rs_v = make_rsrc_words(vp, (unsigned)(((size_t)(p.Nk - 1) * p.ldv + D) * 2));
+    constexpr unsigned OOB = 0x80000000u;
+    // K piece q = wave + 4 m: lane -> key (q * 64 + lane) / SPR, physical slot (q * 64 + lane) % SPR; fetches the logical slot
+    // that lives there.  V piece q: chunk c = q * 64 + lane -> panel c >> 7, key (c >> 2) & 31, 8 channels (c & 3) of the panel.
+    unsigned voff_k[PPW], voff_v[PPW];
+#pragma unroll
+    for (int m = 0; m < PPW; ++m) {
+        const int c = (wave + 4 * m) * 64 + lane;
+        const int key = c / SPR, ps = c % SPR;
+        voff_k[m] = (unsigned)((key * p.ldk + ((ps ^ (key & 15)) << 3)) * 2);
+        voff_v[m] = (unsigned)((((c >> 2) & 31) * p.ldv + (c >> 7) * 32 + (c & 3) * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wsm;
+    const unsigned k_tile_stride = (unsigned)(KVW * p.ldk * 2), v_tile_stride = (unsigned)(KVW * p.ldv * 2);
+    auto stage = [&](int t, int buf) {
+        const unsigned dst = lds0 + (unsigned)(buf * TILE_BYTES) + (unsigned)(wave * 1024);
+        const unsigned kt_off = (unsigned)t * k_tile_stride, vt_off = (unsigned)t * v_tile_stride;
+#pragma unroll
+        for (int m = 0; m < PPW; ++m) dma16(rs_k, dst + m * 4096, voff_k[m] + kt_off, 0);
+#pragma unroll
+        for (int m = 0; m < PPW; ++m) dma16(rs_v, dst + K_BYTES + m * 4096, voff_v[m] + vt_off, 0);
+    };
+
+    // Q fragments of this wave's slice (B operand: lane = query l31, k-half hi), softmax scale * log2(e) folded in
+    const int qrow = qb * 32 + l31;
+    f16x8 qf[KSW];
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) {
+        U4H8 t;
+        t.u = make_uint4(0, 0, 0, 0);
+        if (qrow < p.Nq) t.u = *reinterpret_cast<const uint4*>(qp + (size_t)qrow * p.ldq + wave * DW + ks * 16 + hi * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.e[j] = (f16)((float)t.e[j] * p.scale_log2);
+        qf[ks] = t.h;
+    }
+    f32x16 acc[DBW];
+#pragma unroll
+    for (int i = 0; i < DBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;   // running max (log2 units) and row sum of this lane's query (its key half)
+
+    const int ntiles = (p.Nk + KVW - 1) / KVW;
+    // K fragment of k-step ks: key row l31, logical slot wave * DW / 8 + 2 ks + hi
+    int rd_k[KSW];
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) rd_k[ks] = l31 * (D * 2) + (((wave * (DW / 8) + 2 * ks + hi) ^ (l31 & 15)) << 4);
+    const unsigned v_lane = (unsigned)(K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_h4_ptr;
+
+    stage(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) asm volatile("" ::"v"(qf[ks]));   // the compiler's own vmcnt(0) for the Q loads lands here
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        wait_vmcnt<0>();
+        __syncthreads();   // tile t has landed for every wave; every wave has left tile t - 1 (its stage is refilled below)
+        if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+        const char* Ks = wsm + cur * TILE_BYTES;
+        // ---- partial S^T of this wave's slice
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+            U4H8 a;
+            a.u = *reinterpret_cast<const uint4*>(Ks + rd_k[ks]);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], st, 0, 0, 0);
+        }
+        // ---- exchange: [wave][group g][lane] float4, double-buffered over tiles (one barrier per tile)
+        float* xw = reinterpret_cast<float*>(wsm + 2 * TILE_BYTES + cur * XCH_BYTES);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(xw + ((wave * 4 + g) * 64 + lane) * 4) = make_float4(st[4 * g], st[4 * g + 1], st[4 * g + 2], st[4 * g + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(xw + ((w2 * 4 + g) * 64 + lane) * 4);
+                st[4 * g] += v.x; st[4 * g + 1] += v.y; st[4 * g + 2] += v.z; st[4 * g + 3] += v.w;
+            }
+        // ---- online softmax for query `qrow`; this lane sees keys key0 + (r & 3) + 8 (r >> 2) + 4 hi
+        const int key0 = t * KVW;
+        if (key0 + KVW > p.Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) st[r] = -INFINITY;
+        }
+        float mx = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (t == 0 || __any(mx - m_run > RESCALE_THR)) {
+            const float m_new = (t == 0) ? mx : fmaxf(mx, m_run);
+            if (t != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DBW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+            }
+            m_run = m_new;
+        }
+        f16x8 pb[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[r] - m_run);
+            l_run += e;
+            pb[r >> 3][r & 7] = (f16)e;
+        }
+        // ---- O^T[slice] += V^T[slice] P^T: panels DBW * wave .. of the V image, transposed on the way in
+        const lds_h4_ptr vbase = (lds_h4_ptr)(size_t)(lds0 + (unsigned)(cur * TILE_BYTES) + v_lane);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < DBW; ++i) {
+                const int off8 = ((wave * DBW + i) * KVW * 64 + 16 * s2 * 64) / 8;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vbase + off8);
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(vbase + off8 + 64);
+                const f16x8 a = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[s2], acc[i], 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+    if (qrow < p.Nq) {
+#pragma unroll
+        for (int i = 0; i < DBW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = (wave * DBW + i) * 32 + 8 * g + 4 * hi;
+                U2H4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o.e[j] = (f16)(acc[i][g * 4 + j] * inv);
+                *reinterpret_cast<uint2*>(op + (size_t)qrow * p.ldo + d0) = o.u;
+            }
+    }
+}
+
+template <int D>
+int launch_attn_wide(AttnArgs a, hipStream_t stream) {
+    constexpr int LDS = 2 * (2 * 32 * D * 2) + 2 * (4 * 64 * 16 * 4);
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            vd_set_error("vd_attention_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+            return VD_ERR_LAUNCH;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    a.nqb = (a.Nq + 31) / 32;
+    hipLaunchKernelGGL(attn_wide_kernel<D>, dim3(a.nqb * a.BH), dim3(256), LDS, stream, a);
+    return vd_check_launch("vd_attention_f16");
+}
+
 template <typename OUT>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, OUT* pout, int n, float scale) {
     const size_t row = blockIdx.x;
@@ -389,13 +589,19 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     a.BH = B * H;
     static const char* ctx_env = getenv("VD_ATTN_CTXMAP");   // development switch: 0 = always the K/V-locality mapping
     a.ctx_map = (Nk <= 2 * KV && ((B * a.nqb) & 7) == 0 && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
+    if (H == 1 && (D == 128 || D == 256 || D == 512)) {   // one wide head: head dim split over the waves of a block
+        VD_REQUIRE(causal == 0, "vd_attention_f16: the wide single-head kernel has no causal mask");
+        if (D == 128) return launch_attn_wide<128>(a, stream);
+        if (D == 256) return launch_attn_wide<256>(a, stream);
+        return launch_attn_wide<512>(a, stream);
+    }
     switch (D) {
         case 40: return launch_attn<40>(a, stream);
         case 64: return launch_attn<64>(a, stream);
         case 80: return launch_attn<80>(a, stream);
         case 160: return launch_attn<160>(a, stream);
         default:
-            vd_set_error("vd_attention_f16: unsupported head dim %d (supported: 40, 64, 80, 160)", D);
+            vd_set_error("vd_attention_f16: unsupported head dim %d (supported: 40, 64, 80, 160; one head of 128 / 256 / 512)", D);
             return VD_ERR_UNSUPPORTED;
     }
 }

@@ -3,8 +3,10 @@
 Module tree and state-dict keys follow the reference (lib/model_zoo/autokl_modules.py there: Normalize :38-39,
 Upsample :42-57, Downsample :60-79, ResnetBlock :82-141, AttnBlock :150-202, Encoder :368-459, Decoder :462-568).
 Convs are implicit MFMA GEMMs with the nearest-2x upsample / the asymmetric (0,1,0,1) stride-2 padding folded into
-the gather; GroupNorm(eps 1e-6)+swish is one pass; the single-head mid attention (C=512, N=HW) runs as batched
-GEMMs with fp32 logits (fp16 would overflow there) and a row-softmax kernel."""
+the gather; GroupNorm(eps 1e-6)+swish is one pass; the single-head mid attention (C=512, N=HW) is one fused q|k|v
+projection + vd_attention_f16's wide single-head kernel (online softmax, no [N, N] scores; other widths: batched GEMMs with
+fp32 logits and a row-softmax kernel)."""
+import torch
 import torch.nn as nn
 
 from vd_hip import ops
@@ -74,11 +76,21 @@ class AttnBlock(nn.Module, PackCache):
         B, H, W, C = x.shape
         N = H * W
         hn = self.norm(x, silu=False)
+        if C in (128, 256, 512):
+            # one wide head: q | k | v from ONE 1x1 projection, then vd_attention_f16's single-head kernel (head dim split over
+            # the waves of a block, online softmax): no [N, N] score tensor -- the reference's two torch.bmm around a softmax
+            # (autokl_modules.py:186-198 there) materialise 67 MB per sample at 512x512, 340 MB at 768x768
+            wqkv, bqkv = self._packed("qkv", (self.q.weight, self.q.bias, self.k.weight, self.k.bias, self.v.weight, self.v.bias),
+                                      lambda: (torch.cat([_h(m.weight).reshape(C, C) for m in (self.q, self.k, self.v)], 0).contiguous(),
+                                               torch.cat([_h(m.bias) for m in (self.q, self.k, self.v)], 0).contiguous()))
+            qkv = ops.linear(hn.view(B, N, C), wqkv, bqkv)
+            o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1, scale=float(C) ** -0.5)
+            return self.proj_out(o.view(B, H, W, C), res=x)
         q = self.q(hn).view(B, N, C)
         k = self.k(hn).view(B, N, C)
         wv, bv = self._packed("v", (self.v.weight, self.v.bias),
                               lambda: (_h(self.v.weight).reshape(C, C).contiguous(), _h(self.v.bias)))
-        # V^T[b] = Wv hn[b]^T + bv  -> [B, C, N]: the K-contiguous operand the P.V GEMM wants, no transpose pass
+        # other widths: V^T[b] = Wv hn[b]^T + bv  -> [B, C, N], fp32 scores, row softmax, P.V GEMM
         vt = ops.gemm(wv, hn.view(B, N, C), bias=bv, bias_along_m=True, M=C, N=N, K=C, batch=B,
                       strides=(0, N * C, C * N, 0))
         s = ops.gemm(q, k, M=N, N=N, K=C, batch=B, strides=(N * C, N * C, N * N, 0), alpha=float(C) ** -0.5,
