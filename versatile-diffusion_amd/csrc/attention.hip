@@ -26,7 +26,6 @@ namespace {
 #define VD_ATTN_MINW 1
 #endif
 constexpr int KV = 64;    // keys per tile
-constexpr int QB = 128;   // queries per block (4 waves x 32)
 constexpr float RESCALE_THR = 6.0f;  // log2 units: P values stay <= 64 between rescales
 
 struct AttnArgs {
@@ -42,8 +41,11 @@ struct AttnArgs {
     int ctx_map;   // block -> (batch, head, query block) mapping for short contexts, see the kernel
 };
 
-template <int D>
-__global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_kernel(const AttnArgs p) {
+// NWV waves per block (4, or 8 for long self-attention: the K / V tile's LDS-DMA requests are shared by twice the queries, and
+// request issue is serial time in a wave -- 4 pieces per tile and wave become 2).
+template <int D, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1)) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int QB = 32 * NWV;            // queries per block
     constexpr int KS = (D + 15) / 16;       // k-steps of the QK^T MFMA
     constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T == 32-column panels of the V image
     constexpr int CPR = 2 * KS + 1;         // 16-byte chunks per K row in LDS: data, zero pad to KS*16, +1 (odd stride)
@@ -102,19 +104,20 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
     const i32x4 rs_v = make_rsrc_words(vp, (unsigned)(((size_t)(p.Nk - 1) * p.ldv + D) * 2));
     constexpr unsigned OOB = 0x80000000u;
     // wave w issues K instructions w, w+4, ... (< CPR) and V instructions w, w+4, ... (4*DB of them: DB per wave)
-    constexpr int KM = (CPR + 3) / 4;
-    unsigned voff_k[KM], voff_v[DB];
+    constexpr int KM = (CPR + NWV - 1) / NWV;
+    constexpr int VM = (4 * DB + NWV - 1) / NWV;   // V pieces (4 per panel) per wave
+    unsigned voff_k[KM], voff_v[VM];
 #pragma unroll
     for (int m = 0; m < KM; ++m) {
-        const int q = (wave + 4 * m) * 64 + lane;
+        const int q = (wave + NWV * m) * 64 + lane;
         const int r = q / CPR, slot = q - r * CPR;
         voff_k[m] = (slot * 8 < D) ? (unsigned)((r * p.ldk + slot * 8) * 2) : OOB;
     }
 #pragma unroll
-    for (int m = 0; m < DB; ++m) {
-        const int q = (wave + 4 * m) * 64 + lane;
+    for (int m = 0; m < VM; ++m) {
+        const int q = (wave + NWV * m) * 64 + lane;
         const int d0 = (q >> 8) * 32 + (q & 3) * 8;
-        voff_v[m] = (d0 < D) ? (unsigned)((((q >> 2) & 63) * p.ldv + d0) * 2) : OOB;
+        voff_v[m] = (d0 < D && (wave + NWV * m) < 4 * DB) ? (unsigned)((((q >> 2) & 63) * p.ldv + d0) * 2) : OOB;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_all;
     const unsigned k_tile_stride = (unsigned)(KV * p.ldk * 2), v_tile_stride = (unsigned)(KV * p.ldv * 2);
@@ -123,24 +126,25 @@ __global__ __launch_bounds__(256, (D <= 64 ? VD_ATTN_MINW : 1)) void attn_fwd_ke
         const unsigned kt_off = (unsigned)t * k_tile_stride, vt_off = (unsigned)t * v_tile_stride;
 #pragma unroll
         for (int m = 0; m < KM; ++m)
-            if (m < CPR / 4 || wave < CPR % 4) dma16(rs_k, dst + m * 4096, voff_k[m] + kt_off, 0);
+            if (m < CPR / NWV || wave < CPR % NWV) dma16(rs_k, dst + m * (NWV * 1024), voff_k[m] + kt_off, 0);
 #pragma unroll
-        for (int m = 0; m < DB; ++m) dma16(rs_v, dst + K_BYTES + m * 4096, voff_v[m] + vt_off, 0);
+        for (int m = 0; m < VM; ++m)
+            if (m < (4 * DB) / NWV || wave < (4 * DB) % NWV) dma16(rs_v, dst + K_BYTES + m * (NWV * 1024), voff_v[m] + vt_off, 0);
     };
 
     // lanes whose V chunk starts at column D of the last panel plant the 1.0 after their own DMA has landed
-    bool ones_lane[DB];
+    bool ones_lane[VM];
 #pragma unroll
-    for (int m = 0; m < DB; ++m) {
-        const int q = (wave + 4 * m) * 64 + lane;
-        ones_lane[m] = HAS_ONES && (q >> 8) == DB - 1 && (q & 3) == ONES_COL / 8;
+    for (int m = 0; m < VM; ++m) {
+        const int q = (wave + NWV * m) * 64 + lane;
+        ones_lane[m] = HAS_ONES && (wave + NWV * m) < 4 * DB && (q >> 8) == DB - 1 && (q & 3) == ONES_COL / 8;
     }
     auto plant_ones = [&](int buf) {
         if constexpr (HAS_ONES) {
 #pragma unroll
-            for (int m = 0; m < DB; ++m)
+            for (int m = 0; m < VM; ++m)
                 if (ones_lane[m])
-                    *reinterpret_cast<f16*>(lds_all + buf * TILE_BYTES + K_BYTES + (wave + 4 * m) * 1024 + lane * 16) = (f16)1.0f;
+                    *reinterpret_cast<f16*>(lds_all + buf * TILE_BYTES + K_BYTES + (wave + NWV * m) * 1024 + lane * 16) = (f16)1.0f;
         }
     };
 
@@ -562,9 +566,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, OUT* 
     for (int i = tid; i < n; i += 256) pr[i] = (OUT)(__expf(sr[i] * scale - mx) * inv);
 }
 
-template <int D>
-int launch_attn(const AttnArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(attn_fwd_kernel<D>, dim3(a.nqb * a.BH), dim3(256), 0, stream, a);
+template <int D, int NWV = 4>
+int launch_attn(AttnArgs a, hipStream_t stream) {
+    constexpr int QB = 32 * NWV;
+    a.nqb = (a.Nq + QB - 1) / QB;
+    a.ctx_map = (a.ctx_map && ((a.BH / a.H * a.nqb) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NWV>), dim3(a.nqb * a.BH), dim3(64 * NWV), 0, stream, a);
     return vd_check_launch("vd_attention_f16");
 }
 
@@ -585,10 +592,12 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
     a.scale_log2 = scale * 1.44269504088896340736f;
     a.causal = causal;
-    a.nqb = (Nq + QB - 1) / QB;
+    a.nqb = 0;   // set by the launcher (queries per block depend on the instantiation)
     a.BH = B * H;
     static const char* ctx_env = getenv("VD_ATTN_CTXMAP");   // development switch: 0 = always the K/V-locality mapping
-    a.ctx_map = (Nk <= 2 * KV && ((B * a.nqb) & 7) == 0 && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
+    a.ctx_map = (Nk <= 2 * KV && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
+    static const char* w8_env = getenv("VD_ATTN_W8");        // development switch: 0 = always 4 waves per block
+    const bool w8 = !(w8_env && w8_env[0] == '0') && causal == 0 && Nq >= 2048 && Nk >= 1024;
     if (H == 1 && (D == 128 || D == 256 || D == 512)) {   // one wide head: head dim split over the waves of a block
         VD_REQUIRE(causal == 0, "vd_attention_f16: the wide single-head kernel has no causal mask");
         if (D == 128) return launch_attn_wide<128>(a, stream);
@@ -596,7 +605,7 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
         return launch_attn_wide<512>(a, stream);
     }
     switch (D) {
-        case 40: return launch_attn<40>(a, stream);
+        case 40: return w8 ? launch_attn<40, 8>(a, stream) : launch_attn<40>(a, stream);
         case 64: return launch_attn<64>(a, stream);
         case 80: return launch_attn<80>(a, stream);
         case 160: return launch_attn<160>(a, stream);
