@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 3
+#define VD_HIP_ABI_VERSION 4
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -171,6 +171,20 @@ int vd_row_stats_f16(const void* x, float* stats, int64_t rows, int C, int64_t l
 int vd_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                      int ldq, int ldk, int ldv, int ldo, int64_t sq, int64_t sk, int64_t sv, int64_t so,
                      float scale, int causal, hipStream_t stream);
+
+/* The query side of a cross-attention layer in one launch (vd_xattn_supported: head dim 40 / 80 / 160, width H*D a
+ * multiple of 64):
+ *     out[b, n, h*D..] = softmax( (LayerNorm(x[b, n]) Wq_h^T) K_h^T * scale ) V_h
+ * x, out: fp16 [B][Nq][H*D] contiguous; wq: fp16 [H*D][H*D] with LayerNorm's gamma folded in, bq: fp16 [H*D] = Wq beta (or
+ * NULL), colsum: fp32 [H*D] row sums of the folded wq (the VD_EPI_LNFOLD operands of vd_gemm_f16); k / v [B][Nk][ldk / ldv]
+ * the pre-projected context, head h in columns h*D..h*D+D-1.  Row statistics (biased variance, ln_eps) are accumulated
+ * inside the projection loop; the query tensor never exists in memory.  Replaces norm2 -> to_q -> einsum -> softmax ->
+ * einsum of lib/model_zoo/attention.py:170-193,216 and this library's vd_row_stats_f16 -> vd_gemm_f16(VD_EPI_LNFOLD) ->
+ * vd_attention_f16 chain. */
+int vd_xattn_f16(const void* x, const void* wq, const void* bq, const float* colsum, float ln_eps, const void* k,
+                 const void* v, void* out, int B, int H, int Nq, int Nk, int D, int ldk, int ldv, int64_t sk, int64_t sv,
+                 float scale, hipStream_t stream);
+int vd_xattn_supported(int H, int D);
 
 /* Row softmax fp32 [rows][n] -> fp16 (VAE AttnBlock, lib/model_zoo/autokl_modules.py:192). */
 int vd_softmax_rows_f32_f16(const float* s, void* p, int64_t rows, int n, hipStream_t stream);

@@ -218,6 +218,38 @@ def test_ff_geglu_fused(ops, dev, M, offset):
     assert rel_l2(out, chain.float()) < 3e-3
 
 
+@pytest.mark.parametrize("B,H,D,Nq,Nk,offset", [
+    (2, 8, 40, 1024, 77, 0.0), (8, 8, 40, 4096, 77, 0.3), (1, 8, 40, 200, 77, -1.5), (2, 8, 80, 256, 257, 0.0),
+    (8, 8, 80, 1024, 77, 2.0), (2, 8, 160, 64, 514, 0.0), (3, 8, 160, 100, 77, 0.5), (8, 8, 160, 256, 77, 0.0),
+    (1, 8, 40, 130, 64, 0.0), (2, 8, 80, 96, 128, 4.0)])
+def test_xattn_fused(ops, dev, B, H, D, Nq, Nk, offset):
+    """vd_xattn_f16 (LayerNorm -> to_q -> softmax(q k^T) v in one launch) against torch fp32 and against the library's own
+    row_stats -> GEMM -> attention chain: contexts of 77 / 257 / 514 keys (514 = 8 tiles + 2), ragged query blocks, batch x
+    query-block counts that are / are not a multiple of the 8 XCDs, rows with a common offset (in-loop statistics)."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    C = H * D
+    assert ops.xattn_supported(H, D)
+    x = rnd((B, Nq, C), dev, 1.1, 700) + offset
+    wq = rnd((C, C), dev, C ** -0.5, 701)
+    kv = rnd((B, Nk, 2 * C), dev, 1.0, 702)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, device=dev))
+        ln.bias.copy_(0.1 * torch.randn(C, device=dev))
+    w, b, cs = fold_layernorm(wq, None, ln)
+    out = ops.xattn(x, w, b, cs, 1e-5, kv[..., :C], kv[..., C:], H)
+    xn = F.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), 1e-5)
+    q = (xn @ wq.float().t()).view(B, Nq, H, D).transpose(1, 2)
+    k = kv[..., :C].float().view(B, Nk, H, D).transpose(1, 2)
+    v = kv[..., C:].float().view(B, Nk, H, D).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B, Nq, C)
+    assert out.shape == (B, Nq, C) and bool(torch.isfinite(out).all())
+    assert rel_l2(out, ref) < 4e-3
+    qc = ops.linear(x, w, b, colsum=cs, ln_eps=1e-5)
+    chain = ops.attention(qc, kv[..., :C], kv[..., C:], H)
+    assert rel_l2(out, chain.float()) < 4e-3
+
+
 @pytest.mark.parametrize("rows,C,ld", [(1000, 320, 320), (4099, 640, 640), (77, 1280, 1280), (300, 768, 800), (33, 2048, 2048), (5, 64, 64)])
 def test_row_stats(ops, dev, rows, C, ld):
     """vd_row_stats_f16 (statistics of the folded LayerNorm) vs torch fp32, incl. a padded leading dimension, rows that

@@ -14,12 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
 OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "ff_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "ff_fused.hip", "norm.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "conv_halo_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the
 # v_accvgpr_read/write shuffle and lowers the register footprint (2 -> 3 waves/SIMD for head dim 40)
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "xattn_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # GEMM: without it the accumulators bounce AGPR<->VGPR (64 reads + 64 writes) every K tile
                "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "conv_halo.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
@@ -52,15 +53,25 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + os.environ.get("VD_EXTRA_DEFS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
+        objs.append(o)
+        # per-object stamp (source + every header + the command line): an edit of one kernel file recompiles that file only
+        h = hashlib.sha256(" ".join(cmd).encode())
+        for p in [os.path.join(CSRC, s)] + HEADERS:
+            with open(p, "rb") as f:
+                h.update(f.read())
+        ostamp = o + ".stamp"
+        if not force and os.path.exists(o) and os.path.exists(ostamp) and open(ostamp).read().strip() == h.hexdigest():
+            continue
         if verbose:
             print(" ".join(cmd))
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(o)
-    for s, p in procs:
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), ostamp, h.hexdigest()))
+    for s, p, ostamp, odg in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % s)
+        with open(ostamp, "w") as f:
+            f.write(odg)
         if verbose and out:
             print(out.decode())
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

@@ -114,6 +114,11 @@ class CrossAttention(nn.Module, PackCache):
         else:
             if kv is None:
                 kv = self.project_context(context)
+            if ln is not None and x.dim() == 3 and x.is_contiguous() and ops.xattn_supported(self.heads, c // self.heads):
+                # LayerNorm + to_q + attention over the (short) context in ONE launch: q never exists in memory
+                w, b, cs = self._w_q_ln(ln)
+                a = ops.xattn(x, w, b, cs, ln.eps, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
+                return self.to_out[0](a, res=res)
             if ln is None:
                 q = self.to_q(x)
             else:

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vd_row_stats_f16": (_I, [_P, _P, _L, _I, _L, _F, _P]),
     "vd_attention_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P]),
+    "vd_xattn_f16": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _F, _P]),
+    "vd_xattn_supported": (_I, [_I, _I]),
     "vd_softmax_rows_f32_f16": (_I, [_P, _P, _L, _I, _P]),
     "vd_softmax_rows_f32_f32": (_I, [_P, _P, _L, _I, _F, _P]),
     "vd_timestep_embedding_f16": (_I, [_P, _P, _I, _I, _F, _P]),

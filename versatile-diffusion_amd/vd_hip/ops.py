@@ -347,6 +347,43 @@ def attention(q, k, v, heads, *, scale=None, causal=False, out=None):
     return out
 
 
+XATTN_FUSED = os.environ.get("VD_XATTN_FUSED", "1") != "0"   # development switch: 0 = row_stats -> q GEMM -> attention
+
+
+def xattn_supported(heads, D):
+    """True when vd_xattn_f16 is instantiated for this head geometry (and not switched off)."""
+    return XATTN_FUSED and bool(lib().vd_xattn_supported(int(heads), int(D)))
+
+
+def xattn(x, wq, bq, colsum, ln_eps, k, v, heads, *, scale=None):
+    """softmax((LayerNorm(x) wq_h^T) k_h^T * scale) v_h per head in one launch (vd_xattn_f16).  x [B, Nq, C] contiguous;
+    wq / bq / colsum: the LayerNorm-folded query projection (hip_layers.fold_layernorm); k, v [B, Nk, *] last-dim views
+    of the pre-projected context.  Returns [B, Nq, C]."""
+    for t, n in ((x, "x"), (wq, "wq")):
+        _req(t, n)
+    _req(colsum, "colsum", torch.float32)
+    if bq is not None:
+        _req(bq, "bq")
+    for t, n in ((k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(-1) != 1 or t.dim() != 3:
+            raise VdHipError("%s must be a 3-d fp16 GPU tensor with unit inner stride" % n)
+    B, Nq, C = x.shape
+    Nk = k.shape[1]
+    D = C // heads
+    if tuple(wq.shape) != (C, C) or colsum.numel() != C or k.shape[0] != B or v.shape[1] != Nk or k.shape[2] != C or v.shape[2] != C:
+        raise VdHipError("xattn: operand shapes do not match B=%d C=%d" % (B, C))
+    if scale is None:
+        scale = D ** -0.5
+    out = torch.empty((B, Nq, C), dtype=torch.float16, device=x.device)
+    flops = 2.0 * B * Nq * C * C + 4.0 * B * Nq * Nk * C
+    with _Timed(("xattn_kernel<%d>" % D) + ((" Nq=%d Nk=%d B=%d" % (Nq, Nk, B)) if PROFILE_SHAPES else ""), flops,
+                2.0 * (2 * B * Nq * C + C * C + 2 * B * Nk * C)):
+        _check(lib().vd_xattn_f16(_ptr(x), _ptr(wq), _ptr(bq) if bq is not None else None, _ptr(colsum), float(ln_eps),
+                                  _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D, k.stride(1), v.stride(1), k.stride(0),
+                                  v.stride(0), float(scale), _stream()))
+    return out
+
+
 def softmax_rows(s, out=None):
     _req(s, "s", torch.float32)
     n = s.shape[-1]
