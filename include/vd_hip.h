@@ -59,9 +59,11 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
  *    LN(a)[m][k] = (a[m][k] - mean_m) * rstd_m * gamma[k] + beta[k]
  *    sum_k LN(a)[m][k] W[n][k] = rstd_m * ( sum_k a[m][k] W'[n][k] - mean_m * colsum[n] ) + bias'[n]
  * with W' = gamma (*) W (passed as `w`), colsum[n] = sum_k W'[n][k] (fp32) and bias' = beta W^T + bias (passed as `bias`),
- * all prepared once per layer by the host; (mean_m, rstd_m) are read from `ln_stats` (vd_row_stats_f16: one read of A,
- * 8 bytes per row written), so the nn.LayerNorm in front of a projection (lib/model_zoo/attention.py:214-218) costs half
- * a pass over memory instead of a read + write pass.  Plain (non-conv, single-source) A only, no split-K.
+ * all prepared once per layer by the host.  (mean_m, rstd_m): with `ln_stats` == NULL the kernel accumulates sum and sum
+ * of squares of every A row from the operand fragments inside its K loop (biased variance, `ln_eps`), so the nn.LayerNorm in
+ * front of a projection (lib/model_zoo/attention.py:214-218) costs no pass over memory and no launch; otherwise they are
+ * read from `ln_stats` (vd_row_stats_f16: two-pass statistics, one extra read of A).  Plain (non-conv, single-source) A
+ * only, no split-K.
  * A[m][k] is gathered on the fly: m -> (b, oy, ox) over Hout x Wout, k -> (ky, kx, c) with c running
  * over the channels of a0 (c0) then a1 (c1) -- i.e. torch.cat([a0, a1], dim=1) is never materialised --
  * at input pixel ((oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups) (ups=1: nearest 2x upsample
@@ -86,13 +88,14 @@ typedef struct VdGemmDesc {
     int32_t split_k;     /* 0 = heuristic                                                        */
     int64_t stride_a, stride_w, stride_out, stride_res;
     const float* colsum; /* VD_EPI_LNFOLD: fp32 [N] row sums of w                                */
-    float ln_eps;        /* unused by the kernel (the epsilon is applied by vd_row_stats_f16); kept for layout */
+    float ln_eps;        /* VD_EPI_LNFOLD with ln_stats == NULL: epsilon of the in-loop statistics              */
     int32_t reserved;
     int32_t* sync;       /* optional split-K arrival counters: VD_GEMM_SYNC_INTS ints, ZERO before their first use and
                           * private to the stream (launches on one stream are ordered; the kernel leaves them zero).  With
                           * them the last-arriving block of each output tile sums the tile's fp32 slabs (in split order:
                           * results stay run-to-run identical) and runs the fused epilogue itself -- no reduce launch.   */
-    const float* ln_stats; /* VD_EPI_LNFOLD: fp32 [batch*M][2] = (mean, rstd) of every A row (vd_row_stats_f16)      */
+    const float* ln_stats; /* VD_EPI_LNFOLD: NULL (statistics inside the K loop) or fp32 [batch*M][2] = (mean, rstd) of
+                            * every A row from vd_row_stats_f16                                                     */
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -119,7 +122,7 @@ int vd_gemm_set_override(int tile_cfg);
  * tile_cfg = vd_gemm_num_configs() + variant, 0 <= variant < VD_CONV_HALO_VARIANTS (vd_gemm_config_name knows them).
  * Development hook: -1 = planner's choice (default; also the environment variable VD_CONV_HALO), 0 = never (every conv on
  * gemm_f16_kernel), k > 0 = force variant k - 1 where the geometry permits.  Process-global like vd_gemm_set_override. */
-#define VD_CONV_HALO_VARIANTS 10
+#define VD_CONV_HALO_VARIANTS 11
 int vd_conv_halo_set_variant(int setting);
 /* Tuned launch table: a problem (M, N, K, ksize, epilogue class: bit 0 GEGLU, bit 1 LayerNorm fold, bit 2 two-source A) is
  * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table

@@ -40,10 +40,14 @@ def test_round_quantisation_drives_the_split():
     assert plan(2048, 1280, 23040, ks=3, halo=0) == (T128x128, 3)
     # 320 tiles already cover most of a round: no split
     assert plan(8192, 640, 5760, ks=3, halo=0) == (T128x128, 1)
-    # 40 tiles at the 8x8 level: deep split (also with the halo kernel on: 16 patches x column tiles are too few for it)
+    # 40 tiles at the 8x8 level: deep split (also with the halo kernel on: 16 patches x column tiles are too few for it; its
+    # small-M variant -- 128-pixel patches x 32 columns, whole K per block -- is opt-in / forced only)
     for halo in (0, -1):
         cfg, ns = plan(512, 1280, 11520, ks=3, halo=halo)
         assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
+    from vd_hip.loader import lib
+    cfg, ns = plan(512, 1280, 11520, ks=3, halo=11)
+    assert cfg == NCFG + 10 and lib().vd_gemm_config_name(cfg) == b"conv3x3_halo_kernel<128,32,32,32,256,4>"
 
 
 def test_halo_kernel_takes_the_3x3_convolutions():

@@ -147,11 +147,14 @@ def test_gemm_geglu(ops, dev, M, C):
 
 @pytest.mark.parametrize("M,K,N,offset", [(4096, 320, 960, 0.0), (1000, 640, 640, 0.5), (256, 1280, 3840, -2.0), (130, 320, 320, 8.0),
                                           (2048, 328, 192, 0.3)])
-def test_gemm_layernorm_fold(ops, dev, M, K, N, offset):
-    """VD_EPI_LNFOLD: LayerNorm(x) @ W^T + b with the LayerNorm folded into the projection (row statistics taken from
-    the A tiles inside the GEMM) vs nn.LayerNorm followed by the matmul in fp32.  `offset` shifts the row means away from
-    zero (the fold subtracts mean * colsum from the accumulator: the cancellation must stay harmless)."""
+@pytest.mark.parametrize("inloop", [True, False])
+def test_gemm_layernorm_fold(ops, dev, M, K, N, offset, inloop, monkeypatch):
+    """VD_EPI_LNFOLD: LayerNorm(x) @ W^T + b with the LayerNorm folded into the projection vs nn.LayerNorm followed by the
+    matmul in fp32; row statistics from the A fragments inside the K loop (ln_stats NULL, the product path) and from
+    vd_row_stats_f16.  `offset` shifts the row means away from zero (the fold subtracts mean * colsum from the accumulator
+    and the in-loop variance is E[x^2] - mean^2 in fp32: the cancellation must stay harmless)."""
     from lib.model_zoo.hip_layers import fold_layernorm
+    monkeypatch.setattr(ops, "LN_INLOOP", inloop)
     x = rnd((M, K), dev, 1.5, 50) + offset
     w = rnd((N, K), dev, 0.05, 51)
     b = rnd((N,), dev, 0.3, 52)
@@ -436,6 +439,8 @@ def test_conv3x3_concat_rowvec_residual(ops, dev):
     (1, 96, 96, 64, 0, 160, 0, False, True),       # 768^2 latent geometry (96 = 3 patches of 32)
     (8, 16, 16, 640, 0, 1280, 0, True, False),     # split over channel chunks (fp32 slabs + reduce kernel)
     (2, 64, 32, 64, 0, 72, 0, False, False),       # N not a multiple of the column tile
+    (8, 8, 8, 640, 0, 1280, 0, True, True),        # 8x8 level (small-M variant 10: two images x 32 columns per block, whole K)
+    (2, 8, 8, 128, 64, 96, 0, False, False),       # ... with one patch and a concat
 ])
 def test_conv3x3_halo_every_variant(ops, dev, case):
     """conv3x3_halo_kernel: every instantiation (vd_conv_halo_set_variant) and the planner's own choice against torch's fp32
@@ -465,7 +470,7 @@ def test_conv3x3_halo_every_variant(ops, dev, case):
     try:
         for fixup in (False, True):      # channel-chunk split: slabs + reduce kernel / ticketed in-kernel reduction
             ops.HALO_FIXUP = fixup
-            for v in [-1] + list(range(0, 11)):
+            for v in [-1] + list(range(0, 12)):
                 assert lib().vd_conv_halo_set_variant(v) == 0
                 out = ops.conv2d_nhwc(x, wp, b, **kw)
                 assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, (v, fixup)

@@ -18,6 +18,7 @@ const HaloVariant kHalo[VD_CONV_HALO_VARIANTS] = {
     {256, 160, 256, 2, "conv3x3_halo_kernel<256,160,64,160,256,2>"},
     {256, 160, 512, 3, "conv3x3_halo_kernel<256,160,32,160,512,3>"},
     {256, 128, 512, 3, "conv3x3_halo_kernel<256,128,64,64,512,3>"},
+    {128, 32, 256, 4, "conv3x3_halo_kernel<128,32,32,32,256,4>"},
 };
 
 std::atomic<int> g_halo_variant{-2};   // -2: not read from the environment yet; -1: planner; 0: off; k > 0: force variant k - 1
@@ -126,9 +127,31 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
     if (!halo_geometry(a, hv.bm, c)) return 0;
     c.g.tiles_n = (d.N + hv.bn - 1) / hv.bn;
     const int wst = hv.mode == 0 ? 2 : 3;   // weight stages of the mode
-    if (2 * c.halo_bytes + wst * hv.bn * 128 > 160 * 1024) return 0;
+    if (2 * c.halo_bytes + wst * (hv.mode == 4 ? 9 : 1) * hv.bn * 128 > 160 * 1024) return 0;
     const long tiles = (long)c.g.tiles_m * c.g.tiles_n;
-    if (setting < 0 && tiles < 32) return 0;   // 8x8-level layers: too few patches, the weight stream is everything
+    if (setting < 0 && tiles < 32) {
+        // 8x8-level layers: too few 256-pixel patches; they stay on gemm_f16_kernel with a deep split over K.  Opt-in
+        // (VD_CONV_SMALLM=1, or forced as variant 10): 128-pixel patches (two 8x8 images) x 32 output channels with the whole K
+        // range in one block -- no fp32 slabs, no reduce launch, every weight byte fetched by one XCD.  Measured (session Z):
+        // 44 us instead of 43 + the reduce launch for M = 512, N = 1280, K = 11520, 80 instead of 59 + reduce at K = 23040,
+        // and the graph-replayed forward is 0.09 ms SLOWER: 160 blocks of four waves with 32 x 32 wave tiles pay two
+        // ds_read_b128 per MFMA and ~17 LDS-DMA requests per wave and chunk in ONE instruction stream per SIMD (2.2 us per
+        // chunk where the MFMAs need 0.6).
+        static const char* sm_env = getenv("VD_CONV_SMALLM");
+        if (!(sm_env && sm_env[0] == '1')) return 0;
+        const HaloVariant& sv = kHalo[10];
+        if (d.N % sv.bn != 0 || !halo_geometry(a, sv.bm, c)) return 0;
+        c.g.tiles_n = d.N / sv.bn;
+        if (2 * c.halo_bytes + 3 * 9 * sv.bn * 128 > 160 * 1024) return 0;
+        c.chunks_per_split = c.nchunks;
+        *variant_out = 10;
+        *nsplit_out = (d.split_k > 1 && can_split) ? d.split_k : 1;
+        if (*nsplit_out > 1) {
+            c.chunks_per_split = (c.nchunks + *nsplit_out - 1) / *nsplit_out;
+            *nsplit_out = (c.nchunks + c.chunks_per_split - 1) / c.chunks_per_split;
+        }
+        return 1;
+    }
     // split over channel chunks until one round of blocks covers the chip; unit = one tap of one block
     int ns = 1;
     if (d.split_k > 0) {
@@ -165,6 +188,7 @@ int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStrea
         case 5: return launch_conv_halo<256, 128, 64, 64, 512, 2>(c, nsplit, stream);
         case 8: return launch_conv_halo<256, 160, 32, 160, 512, 3>(c, nsplit, stream);
         case 9: return launch_conv_halo<256, 128, 64, 64, 512, 3>(c, nsplit, stream);
+        case 10: return launch_conv_halo<128, 32, 32, 32, 256, 4>(c, nsplit, stream);
         default: return vd_conv_halo_launch_big(conv_args, variant, nsplit, stream);
     }
 }

@@ -65,10 +65,12 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == NW, "waves must tile the block");
     constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr bool CHUNKW = MODE == 4;                  // MODE 4: a weight stage holds all 9 tap tiles of a chunk, one barrier per chunk
     constexpr int WST = MODE == 0 ? 2 : 3;              // weight stages
-    constexpr bool PIN = MODE >= 2;                     // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
+    constexpr bool PIN = MODE == 2 || MODE == 3;        // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
     constexpr bool SPREAD = MODE == 3;                  // MODE 3: MODE 2 with the LDS-DMA requests of a tap issued one per MFMA gap
-    constexpr int WSTAGE = BN * 128;                    // bytes of one weight tile [BN][64]
+    constexpr int WTILE = BN * 128;                     // bytes of one weight tile [BN][64]
+    constexpr int WSTAGE = CHUNKW ? 9 * WTILE : WTILE;
     constexpr int NPW = BN / 8;                         // 1-KiB DMA pieces (8 rows) of a weight tile
     constexpr int WPW = (NPW + NW - 1) / NW;            // ... per wave
     constexpr int HPXMAX = BM * 100 / 64 + 16;          // bound on halo pixels (checked by the launcher)
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         constexpr int j = decltype(jt)::value;
         if (!dma_on) return;
         const int q = j * NW + wave_s;
-        if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + q * 1024), wvoff[j], (unsigned)((tap * ctot + c * 64) * 2));
+        if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + (CHUNKW ? tap * WTILE : 0) + q * 1024), wvoff[j], (unsigned)((tap * ctot + c * 64) * 2));
     };
 
     // acc[i][j]: TRANSPOSED 32x32 sub-tile (MFMA A operand = weight rows, B operand = pixels): a lane owns output pixel
@@ -263,12 +265,83 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     {
         const ChunkSrc cs0 = chunk_src(c_begin);
         static_for<0, MAXHP>([&](auto jt) { issue_halo(jt, cs0, lds0); });
-        issue_w(c_begin, 0, 0);
-        if constexpr (MODE != 0) issue_w(c_begin, 1, 1);
+        if constexpr (CHUNKW) {
+            static_for<0, 9>([&](auto tt) {
+                static_for<0, WPW>([&](auto jt) { issue_w_piece(jt, c_begin, decltype(tt)::value, 0); });
+            });
+            if (ncl > 1) {
+                static_for<0, 9>([&](auto tt) {
+                    static_for<0, WPW>([&](auto jt) { issue_w_piece(jt, c_begin + 1, decltype(tt)::value, 1); });
+                });
+            }
+        } else {
+            issue_w(c_begin, 0, 0);
+            if constexpr (MODE != 0) issue_w(c_begin, 1, 1);
+        }
     }
 
     if (HALO_ABL(p, 3)) dma_on = false;
-    if constexpr (MODE == 0) {
+    if constexpr (CHUNKW) {
+        // ---- small-M layers (8x8 images: a handful of patches, the weight stream is everything): narrow column tiles, the
+        // whole K range in one block (no split-K slabs), ONE barrier per chunk, three weight stages of 9 tap tiles each.
+        // While chunk lc is multiplied, the halo of chunk lc + 1 (L2-resident activations) is requested behind its first
+        // k-steps and the weight tiles of chunk lc + 2 (HBM) behind the following ones, one piece per k-step (a wave has its
+        // SIMD to itself here: a burst of requests would idle the matrix pipe for its whole issue time).  The wait at the top
+        // of a chunk is counted: the weight pieces requested during the previous chunk -- always the youngest -- stay in flight,
+        // so weights have two chunks of time to arrive from HBM.
+        constexpr int WMIN = 9 * (NPW / NW);          // weight pieces EVERY wave issues per chunk
+        constexpr int NREQ = MAXHP + 9 * WPW;         // request slots per chunk: halo pieces first, then weight pieces
+        static_assert(NREQ <= 36 && WMIN < 64, "one request per k-step");
+        int stg = 0;                                  // lc % 3
+        for (int lc = 0; lc < ncl; ++lc) {
+            const int c = c_begin + lc;
+            const int halo_off = (lc & 1) * p.halo_bytes;
+            const unsigned nxt_halo = lds0 + (unsigned)(((lc & 1) ^ 1) * p.halo_bytes);
+            const bool more = lc + 1 < ncl, more2 = lc + 2 < ncl;
+            const ChunkSrc csn = chunk_src(more ? c + 1 : c);
+            const int stg2 = stg == 0 ? 2 : stg - 1;  // (lc + 2) % 3: the stage of chunk lc - 1
+            if (more) wait_vm<WMIN>();       // this chunk's halo and weight tiles have landed (chunk lc + 1's weights may fly) ...
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();    // ... for every wave; every wave has left the previous chunk
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                hrow[i] = hp_base[i];
+                asm volatile("" : "+v"(hrow[i]));
+            }
+            const char* wchunk = w_smem + stg * WSTAGE;
+            // operand fragments one k-step ahead in two register sets: with one wave per SIMD nothing else hides the LDS
+            // latency of a read that the next MFMA waits for
+            f16x8 af[2][MI], wf[2][NI];
+            {
+                const TapAddr ta0 = tap_addr(halo_off, 0);
+                read_frags(wchunk, ta0, 0, af[0], wf[0]);
+            }
+            static_for<0, 9>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
+                const char* wst = wchunk + t * WTILE;
+                static_for<0, 4>([&](auto kt) {
+                    constexpr int ks = decltype(kt)::value;
+                    constexpr int slot = t * 4 + ks;      // request slot of this k-step
+                    if constexpr (ks < 3) {
+                        read_frags(wst, ta, ks + 1, af[(slot + 1) & 1], wf[(slot + 1) & 1]);
+                    } else if constexpr (t < 8) {
+                        const TapAddr tn_ = tap_addr(halo_off, tapoff_of(t + 1));
+                        read_frags(wst + WTILE, tn_, 0, af[(slot + 1) & 1], wf[(slot + 1) & 1]);
+                    }
+                    mma(af[slot & 1], wf[slot & 1]);
+                    if constexpr (slot < MAXHP) {
+                        if (more) issue_halo(std::integral_constant<int, slot>{}, csn, nxt_halo);
+                    } else if constexpr (slot < NREQ) {
+                        constexpr int wq = slot - MAXHP;
+                        if (more2) issue_w_piece(std::integral_constant<int, wq % WPW>{}, c + 2, wq / WPW, stg2);
+                    }
+                });
+            });
+            stg = stg == 2 ? 0 : stg + 1;
+        }
+    } else if constexpr (MODE == 0) {
         // ---- one barrier at the top of every tap
         for (int lc = 0; lc < ncl; ++lc) {
             const int c = c_begin + lc;
@@ -584,7 +657,7 @@ template <int BM, int BN, int WM, int WN, int NT, int MODE>
 int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
     constexpr int WST = MODE == 0 ? 2 : 3;
     constexpr int EPI = BM * (BN + 8) * 2;
-    const int main_bytes = 2 * a.halo_bytes + WST * BN * 128;
+    const int main_bytes = 2 * a.halo_bytes + WST * (MODE == 4 ? 9 : 1) * BN * 128;
     const int lds = main_bytes > EPI ? main_bytes : EPI;
     if (lds > 160 * 1024) {
         vd_set_error("conv3x3_halo: %d bytes of LDS", lds);

@@ -439,12 +439,33 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         rd_b[ks] = BMP * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
     }
     f16x8 fa[FB][MI], fb[FB][NI];  // (double-buffered) operand fragments; indices are compile-time after unrolling
+    // LayerNorm fold without a statistics pass (d.ln_stats == NULL): every A fragment passes through read_frags exactly once,
+    // and a lane's fragments all belong to ONE row per 32-row block (row l31, k-half hi) -- sum and sum of squares of that row
+    // are two v_dot2_f32_f16 per register on the way (8 VALU instructions per fragment, issued beside the MFMAs), the other
+    // half of the row is one lane^32 exchange in the epilogue.  (Round 2 did this with converts + FMAs, 3x the instructions,
+    // and it cost as much as the statistics launches it removed.)
+    const bool ln_inloop = LNF && d.ln_stats == nullptr;
+    float ls1[MI], ls2[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ls1[i] = ls2[i] = 0.f;
     auto read_frags = [&](const char* st, int ks, f16x8* a, f16x8* b) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             U4H8 t;
             t.u = *reinterpret_cast<const uint4*>(st + rd_a[ks] + i * 32 * KROW_BYTES);
             a[i] = t.h;
+            if constexpr (LNF) {
+                if (ln_inloop) {
+                    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                    const f16x2_t one2 = {(_Float16)1.0f, (_Float16)1.0f};
+                    const f16x2_t* pr = reinterpret_cast<const f16x2_t*>(&t);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ls1[i] = __builtin_amdgcn_fdot2(pr[q], one2, ls1[i], false);
+                        ls2[i] = __builtin_amdgcn_fdot2(pr[q], pr[q], ls2[i], false);
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -802,9 +823,19 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         if ((e.flags & VD_EPI_BIAS) && (e.flags & VD_EPI_BIAS_ALONG_M) && row < d.M) bm = (float)e.bias[row];
         float ln_rstd = 1.f, ln_nmr = 0.f;  // y = rstd * acc - (mean * rstd) * colsum[n] + bias'[n]
         if (lnf) {
-            const float2 st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
-            ln_rstd = st.y;
-            ln_nmr = -st.x * st.y;
+            if (ln_inloop) {
+                const float s1 = ls1[i] + __shfl_xor(ls1[i], 32, 64), s2 = ls2[i] + __shfl_xor(ls2[i], 32, 64);
+                const float inv_k = 1.0f / (float)d.K;
+                const float mean = s1 * inv_k;
+                float var = s2 * inv_k - mean * mean;
+                if (var < 0.f) var = 0.f;
+                ln_rstd = rsqrtf(var + d.ln_eps);
+                ln_nmr = -mean * ln_rstd;
+            } else {
+                const float2 st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
+                ln_rstd = st.y;
+                ln_nmr = -st.x * st.y;
+            }
         }
         if (geglu) {
             // weight rows are packed per 64-row group as [32 value rows | 32 gate rows]: of each pair of 32-column MFMA

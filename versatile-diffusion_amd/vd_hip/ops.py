@@ -194,8 +194,10 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if conv is not None or a1 is not None or max(batch, 1) != 1:
             raise VdHipError("gemm: the LayerNorm fold takes a plain single-source, unbatched A")
         flags |= EPI_LNFOLD
-        ln_stats = row_stats(a0, int(K), int(M), float(ln_eps), ldx=int(lda0) if lda0 else int(K))
-        d.colsum, d.ln_eps, d.ln_stats = colsum.data_ptr(), float(ln_eps), ln_stats.data_ptr()
+        d.colsum, d.ln_eps = colsum.data_ptr(), float(ln_eps)
+        if not LN_INLOOP:   # two-pass statistics from their own launch instead of the K loop's running sums
+            ln_stats = row_stats(a0, int(K), int(M), float(ln_eps), ldx=int(lda0) if lda0 else int(K))
+            d.ln_stats = ln_stats.data_ptr()
     d.flags, d.act, d.alpha = flags, int(act), float(alpha)
     d.batch, d.split_k = int(batch), int(split_k)
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = [int(s) for s in strides]
@@ -239,6 +241,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     return out
 
 
+LN_INLOOP = os.environ.get("VD_LN_INLOOP", "0") == "1"   # 1 = LN statistics inside the K loop of the folded GEMM (measured neutral: +3..7 us per GEMM = the vd_row_stats_f16 launches it removes; the two-pass statistics stay the default)
 FF_FUSED = os.environ.get("VD_FF_FUSED", "1") != "0"   # development switch: 0 = always the three-launch chain
 
 
