@@ -431,6 +431,51 @@ def test_oracle_against_live_reference_on_random_cases(tiny_sd, meta, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
+def test_oracle_against_live_reference_at_full_width(tmp_path):
+    """The oracle pinned at the width the GPU parity tests use it at: VD_v2_0 built by the REFERENCE's registry from its own
+    YAML configs (openai_unet_2d_v1, 859.5 M parameters; openai_unet_0d_v1_dc, 1.71 B), synthetic weights regenerated by
+    name on both sides, 16x16 latent, L = 77 text / 257 image tokens (separate process, oracle/ref_live_fullwidth.py):
+    single-context and mixed-context forwards of the image flow, the text-latent (0-D) flow with either context, and a
+    4-step guided DDIM loop replayed through the oracle: forwards < 2e-5, final latent < 1e-4 rel-L2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "fullwidth.npz")
+    seed = 7
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "ref_live_fullwidth.py"), out, str(seed)],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(out)
+    assert [int(v) for v in d["nparams"]] == [859520964, 1706797888]
+    sys.path.insert(0, os.path.join(root, "versatile-diffusion_amd"))
+    from lib.cfg_helper import CfgDict, model_cfg_bank
+    from lib.model_zoo import get_model
+    bank = model_cfg_bank()
+    cfg = CfgDict(type="vd_v2_0", args=CfgDict(
+        vae_cfg_list=[], ctx_cfg_list=[["image", "ctx-image-placeholder"], ["text", "ctx-text-placeholder"]],
+        diffuser_cfg_list=[["image", bank("openai_unet_2d_v1")], ["text", bank("openai_unet_0d_v1_dc")]],
+        global_layer_ptr="image", latent_scale_factor={"image": 0.18215}, beta_linear_start=0.00085,
+        beta_linear_end=0.012, timesteps=1000, use_ema=False))
+    with torch.device("meta"):       # key names and shapes only (this package's modules mirror the reference's layout)
+        shapes = synth.shapes_of(get_model()(cfg, verbose=False))
+    sd = synth.synth_state_dict(shapes, seed)
+    sd.update(O.register_schedule())
+    g = lambda n: T(d[n])
+    x, t, ct, ci, x0d = g("x"), g("t").long(), g("ct"), g("ci"), g("x0d")
+    p2, p0 = O.unet_plan(**dict(bank("openai_unet_2d_v1").args)), O.unet0d_plan(**dict(bank("openai_unet_0d_v1_dc").args))
+    with torch.no_grad():
+        assert rel(O.apply_model(sd, p2, x, t, ct, c_type="text", global_ptr="image"), g("e_t")) < 2e-5
+        assert rel(O.apply_model(sd, p2, x, t, ci, c_type="image", global_ptr="image"), g("e_i")) < 2e-5
+        mix = O.apply_model_multicontext(sd, p2, x, t, [("text", ct, 0.4), ("image", ci, 0.6)], global_ptr="image")
+        assert rel(mix, g("e_m")) < 2e-5
+        assert rel(O.apply_model(sd, p0, x0d, t, ct, x_type="text", c_type="text", global_ptr="image"), g("e0_t")) < 2e-5
+        assert rel(O.apply_model(sd, p0, x0d, t, ci, x_type="text", c_type="image", global_ptr="image"), g("e0_i")) < 2e-5
+        c_text = {"type": "text", "conditioning": ct, "unconditional_conditioning": g("ut"), "ratio": 1.0}
+        z, _ = O.ddim_sample(sd, p2, sd["alphas_cumprod"], g("xT"), [c_text], 4, 7.5, global_ptr="image")
+        assert rel(z, g("z")) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/model_zoo"), reason="reference checkout not present")
 def test_optimus_oracle_against_live_reference_on_random_cases(tmp_path):
     """GPT-2 latent-connector logits (random sequence lengths 1-19, batches 1-3) and BERT latent-connector outputs (random
     right-padded batches, lengths 2-29, incl. rows without padding) from the LIVE reference classes (separate process,
