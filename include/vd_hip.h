@@ -131,6 +131,17 @@ int vd_conv_halo_set_variant(int setting);
 int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
 int vd_gemm_tune_clear(void);
 
+/* y[M][N] = [LayerNorm](x[M][320]) W[N][320]^T + bias (+ res) with the block's 128 rows of x resident in registers (no activation
+ * tile, no activation DMA): the K = 320 projections of the UNet's 64x64 level (proj_in / proj_out / to_out, N = 320; the fused
+ * q | k | v projection, N = 960, with the LayerNorm applied in registers).  x: fp16 [M][320] contiguous; w: fp16 [N][320]
+ * (gamma-folded when layernorm != 0), bias: fp16 [N] or NULL (beta W^T + bias when layernorm != 0), res: fp16 [M][N] or NULL,
+ * y: fp16 [M][N]; N a multiple of 320 (vd_gemm_row320_supported).  Same result as vd_gemm_f16 on the same operands
+ * (VD_EPI_BIAS | VD_EPI_RESIDUAL | VD_EPI_LNFOLD) up to fp16 rounding of the normalised rows.
+ * Replaces nn.Linear / 1x1 nn.Conv2d of lib/model_zoo/attention.py:159-163,170-193,245-258 at inner width 320. */
+int vd_gemm_row320_f16(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N,
+                       int layernorm, float ln_eps, hipStream_t stream);
+int vd_gemm_row320_supported(int64_t M, int N, int K);
+
 /* The gated feed-forward of a BasicTransformerBlock in one launch (inner width C = 320 only: vd_ff_geglu_supported):
  *     y[m] = res[m] + ( v (*) gelu_erf(g) ) W2^T + b2,     [v | g] = LayerNorm(x[m]) W1^T + b1
  * x, res, y: fp16 [M][C]; w1_packed: fp16 [8C][C] with LayerNorm's gamma folded in (W1 * gamma) and rows packed per 64 as

@@ -221,6 +221,42 @@ def test_ff_geglu_fused(ops, dev, M, offset):
     assert rel_l2(out, chain.float()) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,ln,with_res,offset", [(32768, 320, False, True, 0.0), (32768, 960, True, False, 0.4), (24576 + 40, 320, True, True, -3.0),
+                                                     (32768, 320, False, False, 0.0), (8192 + 5, 960, False, True, 0.0)])
+def test_gemm_row320(ops, dev, M, N, ln, with_res, offset, monkeypatch):
+    """vd_gemm_row320_f16 (rows of x resident in registers, K = 320) against torch fp32 and against gemm_f16_kernel on the same
+    operands; through ops.gemm's dispatch (plain, LayerNorm-folded, with residual, ragged last row block)."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.loader import lib
+    x = rnd((M, 320), dev, 1.1, 900) + offset
+    w = rnd((N, 320), dev, 0.05, 901)
+    b = rnd((N,), dev, 0.3, 902)
+    res = rnd((M, N), dev, 1.0, 903) if with_res else None
+    lnm = torch.nn.LayerNorm(320, eps=1e-5).to(dev)
+    with torch.no_grad():
+        lnm.weight.copy_(1.0 + 0.3 * torch.randn(320, generator=torch.Generator().manual_seed(904)).to(dev))
+        lnm.bias.copy_(0.2 * torch.randn(320, generator=torch.Generator().manual_seed(905)).to(dev))
+    xin = F.layer_norm(x.float(), (320,), lnm.weight.float(), lnm.bias.float(), 1e-5) if ln else x.float()
+    ref = xin @ w.float().t() + b.float() + (res.float() if with_res else 0.0)
+    assert lib().vd_gemm_row320_supported(M, N, 320) == 1 and lib().vd_gemm_row320_supported(M, 480, 320) == 0
+    if ln:
+        wp, bp, cs = fold_layernorm(w, b, lnm)
+        kw = dict(colsum=cs, ln_eps=1e-5)
+    else:
+        wp, bp, kw = w, b, {}
+    out = ops.gemm_row320(x, wp, bp, res, ln, 1e-5)
+    assert out.shape == (M, N) and rel_l2(out, ref) < 3e-3
+    # ops.gemm sends the LayerNorm-folded projections whose row blocks fill the chip here, everything else to gemm_f16_kernel
+    ops.profile_begin()
+    via = ops.gemm(x, wp, bias=bp, res=res, **kw)
+    names = [r[0] for r in ops.profile_end()]
+    assert any(n.startswith("rowgemm320") for n in names) == (ln and ((M + 127) // 128) * (N // 320) >= 192), names
+    assert rel_l2(via, ref) < 3e-3
+    monkeypatch.setattr(ops, "ROW320", False)
+    old = ops.gemm(x, wp, bias=bp, res=res, **kw)
+    assert rel_l2(out, old.float()) < 3e-3
+
+
 @pytest.mark.parametrize("B,H,D,Nq,Nk,offset", [
     (2, 8, 40, 1024, 77, 0.0), (8, 8, 40, 4096, 77, 0.3), (1, 8, 40, 200, 77, -1.5), (2, 8, 80, 256, 257, 0.0),
     (8, 8, 80, 1024, 77, 2.0), (2, 8, 160, 64, 514, 0.0), (3, 8, 160, 100, 77, 0.5), (8, 8, 160, 256, 77, 0.0),

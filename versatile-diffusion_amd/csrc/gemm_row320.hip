@@ -1,0 +1,228 @@
+// vd_gemm_row320_f16: y[M][N] = [LayerNorm](x[M][320]) W[N][320]^T + bias (+ res) for the projections of the 64x64 level of the
+// UNet (K = 320, N = 320 or 960: SpatialTransformer.proj_in / proj_out, CrossAttention.to_out and the LayerNorm-folded fused
+// q | k | v projection; /root/reference/lib/model_zoo/attention.py:159-163,170-193,245-258).
+//
+// Why not gemm_f16_kernel: with K = 320 a tile has five K iterations, so prologue, epilogue and the activation DMA of every
+// (row panel x column tile) block are most of its life (23 us for 6.7 GFLOP, 69 us for the N = 960 projection).  Here the
+// ROWS are what a block keeps: its 128 rows of x live in registers as MFMA operand fragments for the whole launch
+// (ff_geglu_kernel's scheme: a wave's 32 rows x 320 columns = 80 registers, layer-normalised in place when asked), so there is
+// no activation tile in LDS, no activation DMA, no fragment read for it -- per MFMA one ds_read_b128 of the weight tile --
+// and the [128 x 320] fp32 accumulator (80 registers) leaves through one LDS tile as 16-byte row segments (+ residual).
+// Weights stream through three 40-KiB slots ([320 rows][64 k] as two 160-row halves; requested two K tiles ahead, counted
+// vmcnt, one barrier per K tile).  N = 960 runs as three column groups (blockIdx.y), each re-reading x from L2.
+#include "gemm_kernel.h"
+
+namespace {
+
+constexpr int RG_C = 320;
+constexpr int RG_KT = RG_C / 64;
+constexpr int RG_BM = 128;
+constexpr int RG_HALF = 160 * 128;            // bytes of one 160-row half of a K tile
+constexpr int RG_SLOT = 2 * RG_HALF;          // 40 KiB
+constexpr int RG_NSLOT = 3;
+constexpr int RG_CS_LD = RG_C + 8;
+constexpr int RG_LDS_MAIN = RG_NSLOT * RG_SLOT;
+constexpr int RG_LDS_EPI = RG_BM * RG_CS_LD * 2;
+constexpr int RG_LDS = RG_LDS_MAIN > RG_LDS_EPI ? RG_LDS_MAIN : RG_LDS_EPI;
+static_assert(RG_LDS <= 160 * 1024, "LDS budget");
+
+struct RGArgs {
+    const f16* x;      // [M][320]
+    const f16* w;      // [N][320]   (gamma-folded when ln)
+    const f16* bias;   // [N] or null (beta-folded when ln)
+    const f16* res;    // [M][N] or null
+    f16* y;            // [M][N]
+    int M, N;
+    float eps;
+    int nt_store;
+};
+
+template <bool LN>
+__global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * RG_BM;
+    const int n0 = blockIdx.y * RG_C;          // column group of 320
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const i32x4 rs_w = make_rsrc_words(p.w + (size_t)n0 * RG_C, (unsigned)(RG_C * RG_C * 2));
+
+    // a 160-row half = 20 pieces of 8 rows: wave w issues pieces w, w + 8 and (w + 16 < 20 ? w + 16 : w + 8 again: identical
+    // bytes to the identical place) -- every wave issues 6 pieces per K tile, so the waits can be counted
+    unsigned v2[3], d2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int q = j * 8 + wave;
+        if (q >= 20) q -= 8;
+        const int r = q * 8 + (lane >> 3);
+        v2[j] = (unsigned)((r * RG_C + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2);
+        d2[j] = (unsigned)(__builtin_amdgcn_readfirstlane(q) * 1024);
+    }
+    auto issue_kt = [&](int kt, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned soff = (unsigned)((h * 160 * RG_C + kt * 64) * 2);
+            const unsigned dst = lds0 + (unsigned)(slot * RG_SLOT + h * RG_HALF);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dma16(rs_w, dst + d2[j], v2[j], soff);
+        }
+    };
+
+    // ---- x fragments: xf[kt * 4 + ks] = x[row][kt * 64 + ks * 16 + hi * 8 .. + 8] (B operand)
+    const int row = m0 + wm * 32 + l31;
+    const int rowc = row < p.M ? row : p.M - 1;
+    f16x8 xf[RG_KT * 4];
+    {
+        const f16* xr = p.x + (size_t)rowc * RG_C + hi * 8;
+#pragma unroll
+        for (int k = 0; k < RG_KT * 4; ++k) {
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(xr + k * 16);
+            xf[k] = t.h;
+        }
+    }
+    issue_kt(0, 0);
+    issue_kt(1, 1);
+    issue_kt(2, 2);
+
+    if constexpr (LN) {   // LayerNorm in registers: the two lanes l31 / l31 + 32 hold one row between them
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RG_KT * 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += (float)xf[k][i];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / RG_C);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < RG_KT * 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dl = (float)xf[k][i] - mean;
+                q += dl * dl;
+            }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.0f / RG_C) + p.eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int k = 0; k < RG_KT * 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xf[k][i] = (f16)fmaf((float)xf[k][i], rstd, nmr);
+    } else {
+        // the x loads are the only VMEM results the compiler tracks: consume them here so its vmcnt wait does not land inside
+        // the loop (it cannot see the hand-counted DMA requests issued after them)
+#pragma unroll
+        for (int k = 0; k < RG_KT * 4; ++k) asm volatile("" ::"v"(xf[k]));
+    }
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd[ks] = wn * RG_HALF + lds_off_kb<64>(l31, ks * 2 + hi);   // + slot * RG_SLOT + j * 32 * 128
+
+#pragma unroll
+    for (int kt = 0; kt < RG_KT; ++kt) {
+        // K tile kt has landed; the tiles requested after it (kt + 1, and kt + 2 at the first step) may still be in flight
+        if (kt == 0) wait_vm<12>();
+        else if (kt + 1 < RG_KT) wait_vm<6>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();   // ... for every wave; every wave has left K tile kt - 1, whose slot is refilled now
+        asm volatile("" ::: "memory");
+        if (kt >= 1 && kt + 2 < RG_KT) issue_kt(kt + 2, (kt + 2) % RG_NSLOT);
+        const char* st = smem + (kt % RG_NSLOT) * RG_SLOT;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                U4H8 wf;
+                wf.u = *reinterpret_cast<const uint4*>(st + rd[ks] + j * 32 * 128);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, xf[kt * 4 + ks], acc[j], 0, 0, 0);
+            }
+    }
+    __syncthreads();   // every wave is done with the slots: the output tile re-uses that LDS
+
+    // ---- epilogue: + bias -> fp16 tile in LDS -> 16-byte row segments (+ residual) -> y
+    f16* cs = reinterpret_cast<f16*>(smem);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = wn * 160 + j * 32 + 8 * g + 4 * hi;
+            U2H4 b, o;
+            b.u = make_uint2(0, 0);
+            if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + n0 + col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.e[q] = (f16)(acc[j][g * 4 + q] + (float)b.e[q]);
+            *reinterpret_cast<uint2*>(cs + (wm * 32 + l31) * RG_CS_LD + col) = o.u;
+        }
+    __syncthreads();
+    constexpr int CH = RG_C / 8;                       // 40 segments per row
+    constexpr int PER = RG_BM * CH / 512;              // 10 per thread
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int sgm = tid + k * 512;
+        const int r = sgm / CH, cc = (sgm % CH) * 8;
+        const int grow = m0 + r;
+        if (grow < p.M) {
+            U4H8 t, o;
+            t.u = *reinterpret_cast<const uint4*>(cs + r * RG_CS_LD + cc);
+            o = t;
+            if (p.res) {
+                U4H8 a;
+                a.u = *reinterpret_cast<const uint4*>(p.res + (size_t)grow * p.N + n0 + cc);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q]);
+            }
+            f16* dst = p.y + (size_t)grow * p.N + n0 + cc;
+            if (p.nt_store) vd_store16_nt(dst, o.u);
+            else *reinterpret_cast<uint4*>(dst) = o.u;
+        }
+    }
+}
+
+template <bool LN>
+int launch_rowgemm(const RGArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm320_kernel<LN>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+        if (e != hipSuccess) {
+            vd_set_error("vd_gemm_row320_f16: cannot reserve %d bytes of LDS: %s", RG_LDS, hipGetErrorString(e));
+            return VD_ERR_LAUNCH;
+        }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    const dim3 grid((unsigned)((a.M + RG_BM - 1) / RG_BM), (unsigned)(a.N / RG_C));
+    hipLaunchKernelGGL(rowgemm320_kernel<LN>, grid, dim3(512), RG_LDS, stream, a);
+    return vd_check_launch("vd_gemm_row320_f16");
+}
+
+}  // namespace
+
+extern "C" int vd_gemm_row320_supported(int64_t M, int N, int K) {
+    return (K == RG_C && N > 0 && N % RG_C == 0 && M > 0 && M < (1ll << 31) / N) ? 1 : 0;
+}
+
+extern "C" int vd_gemm_row320_f16(const void* x, const void* w, const void* bias, const void* res, void* y, int64_t M, int N,
+                                  int layernorm, float ln_eps, hipStream_t stream) {
+    VD_REQUIRE(x && w && y, "vd_gemm_row320_f16: null pointer");
+    VD_REQUIRE(vd_gemm_row320_supported(M, N, RG_C), "vd_gemm_row320_f16: M=%ld N=%d not supported (K = 320, N a multiple of 320)", (long)M, N);
+    VD_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)res) & 15) == 0 && ((size_t)bias & 7) == 0,
+               "vd_gemm_row320_f16: operands must be 16-byte aligned (bias 8)");
+    RGArgs a;
+    a.x = (const f16*)x; a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.y = (f16*)y;
+    a.M = (int)M; a.N = N; a.eps = ln_eps;
+    static const char* nt_env = getenv("VD_GEMM_NT");
+    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    return layernorm ? launch_rowgemm<true>(a, stream) : launch_rowgemm<false>(a, stream);
+}

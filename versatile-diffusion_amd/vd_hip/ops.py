@@ -151,6 +151,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
+    # (the plain N = 320 projections measure equal on both kernels -- 24.9 vs 24.2 us: with one 128-row block per CU in
+    # lock-step a launch is its load / store phases either way; the LayerNorm-folded q | k | v projection is 59 vs 66 us + the
+    # statistics launch)
+    if ROW320 and colsum is not None and _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k):
+        return gemm_row320(a0, w, bias, res, True, ln_eps, out_shape)
     if not _tune_checked[0]:     # shipped tuned launch table (vd_hip/tune.py), installed on first use
         _tune_checked[0] = True
         from . import tune
@@ -238,6 +243,49 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
     with _Timed(name, 2.0 * nb * M * N * K, 2.0 * (nb * (a_elems + float(N) * K + float(M) * n_out) + extra)):
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
+    return out
+
+
+ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
+
+
+def _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k):
+    """vd_gemm_row320_f16 takes the plain K = 320 projections whose row blocks fill the chip (the UNet's 64x64 level)."""
+    if a1 is not None or rowvec is not None or out is not None or out_f32 or bias_along_m or max(batch, 1) != 1:
+        return False
+    if act != ACT_NONE or alpha != 1.0 or split_k > 1 or w.dim() != 2 or not w.is_contiguous() or not a0.is_contiguous():
+        return False
+    if conv is not None:
+        if conv.get("ksize", 1) != 1 or conv.get("stride", 1) != 1 or conv.get("pad", 0) != 0 or conv.get("ups", 0) != 0:
+            return False
+        if conv["Hin"] != conv["Hout"] or conv["Win"] != conv["Wout"]:
+            return False
+    k = w.shape[1] if K is None else K
+    n = w.shape[0] if N is None else N
+    if k != 320 or a0.shape[-1] != 320 or w.shape[1] != 320 or n != w.shape[0] or n % 320 != 0:
+        return False
+    m = a0.numel() // 320
+    if M is not None and int(M) != m:
+        return False
+    if any(int(v) not in (0, e) for v, e in ((lda0, 320), (ldw, 320), (ldc, n), (ldr, n))):
+        return False
+    if res is not None and (not res.is_contiguous() or res.numel() != m * n):
+        return False
+    return ((m + 127) // 128) * (n // 320) >= 192
+
+
+def gemm_row320(a0, w, bias=None, res=None, layernorm=False, ln_eps=1e-5, out_shape=None):
+    """[LayerNorm](a0 [M, 320]) @ w [N, 320]^T + bias (+ res) with the rows of a0 resident in registers (vd_gemm_row320_f16);
+    with layernorm, w / bias are the folded operands (hip_layers.fold_layernorm)."""
+    for t, nm in ((a0, "a0"), (w, "w"), (bias, "bias"), (res, "res")):
+        _req(t, nm)
+    n = w.shape[0]
+    m = a0.numel() // 320
+    out = torch.empty(out_shape if out_shape is not None else (m, n), dtype=torch.float16, device=a0.device)
+    name = "rowgemm320_kernel" + ((" M=%d N=%d ln=%d" % (m, n, int(layernorm))) if PROFILE_SHAPES else "")
+    with _Timed(name, 2.0 * m * n * 320, 2.0 * (m * 320 + n * 320 + m * n * (2 if res is not None else 1))):
+        _check(lib().vd_gemm_row320_f16(_ptr(a0), _ptr(w), _ptr(bias), _ptr(res), _ptr(out), m, n, 1 if layernorm else 0,
+                                        float(ln_eps), _stream()))
     return out
 
 
@@ -660,7 +708,7 @@ def _guarded(fn):
     return wrapper
 
 
-for _name in ("gemm", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
+for _name in ("gemm", "gemm_row320", "ff_geglu", "xattn", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
               "unary", "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
