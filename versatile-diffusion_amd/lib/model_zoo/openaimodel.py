@@ -9,6 +9,7 @@ skip-connection concat / nearest-2x upsample in place and fold bias, the timeste
 residual add into their epilogue.
 """
 import copy
+import os
 from functools import partial
 
 import numpy as np
@@ -94,6 +95,20 @@ class Downsample(nn.Module):
         return self.op(x)
 
 
+# development switch (VD_RES_FORK=1): the skip 1x1 convolution of a ResBlock on a side stream beside the block's main path.
+# Measured (tools/gpu_r03_ab.sh): 11.22 vs 11.12 ms per graph-replayed forward -- parallel branches lose on this stack.
+RES_FORK = os.environ.get("VD_RES_FORK", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = s
+    return s
+
+
 class ResBlock(TimestepBlock, PackCache):
     """GN+SiLU -> conv3x3 (+bias +emb) -> GN+SiLU -> conv3x3 (+bias +skip(x)); use_scale_shift_norm=False."""
 
@@ -127,10 +142,23 @@ class ResBlock(TimestepBlock, PackCache):
             conv, lin = self.in_layers[2], self.emb_layers[1]
             bias1 = self._packed("b1", (conv.bias, lin.bias),
                                  lambda: (conv.bias.detach().float() + lin.bias.detach().float()).to(torch.float16).contiguous())
+        fork = RES_FORK and x.is_cuda and not isinstance(self.skip_connection, nn.Identity)
+        if fork:
+            # the 1x1 skip convolution depends only on the block's input: it runs on a side stream beside GroupNorm -> conv ->
+            # GroupNorm of the main path and is joined in front of the second conv, which consumes it as its residual.  Its
+            # output is allocated on the MAIN stream (the caching allocator ties a block to its allocation stream).
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            res = torch.empty((B, H, W, self.out_channels), dtype=torch.float16, device=x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.skip_connection(x, x1=skip, out=res)
         h = self.in_layers[0](x, x1=skip, silu=True)
         h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W, bias=bias1)
         h = self.out_layers[0](h, silu=True)
-        if isinstance(self.skip_connection, nn.Identity):
+        if fork:
+            main.wait_stream(side)
+        elif isinstance(self.skip_connection, nn.Identity):
             assert skip is None
             res = x
         else:
