@@ -95,6 +95,21 @@ def test_halo_and_fragment_addresses(nimg, Hin, Win, ups, NW, WM):
     g = geometry(nimg, Hin, Win, ups)
     if g is None:
         pytest.skip("geometry not accepted by the halo launcher (falls back to gemm_f16_kernel)")
+    _check_halo_and_fragments(g, nimg, Hin, ups, NW, WM)
+
+
+@pytest.mark.parametrize("nimg,Hin,Win,ups", [(8, 8, 8, 0), (2, 8, 8, 0), (4, 16, 16, 0), (2, 32, 32, 0), (6, 8, 8, 0)])
+def test_small_m_variant_addresses(nimg, Hin, Win, ups, monkeypatch):
+    """conv3x3_halo_kernel<128,32,32,32,256,4> (variant 10): 128-pixel patches (two whole 8x8 images, 16 x 8 at 16x16, 4 rows x 32
+    columns at 32x32), four waves of 32 pixels -- same index maps with BM = 128."""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "BM", 128)
+    g = geometry(nimg, Hin, Win, ups, BM=128)
+    assert g is not None and g["tiles_m"] == nimg * Hin * Win // 128
+    _check_halo_and_fragments(g, nimg, Hin, ups, 4, 32)
+
+
+def _check_halo_and_fragments(g, nimg, Hin, ups, NW, WM):
     MI = WM // 32
     waves_m = BM // WM
     rng = np.random.RandomState(nimg * 1000 + Hin + ups)
