@@ -222,7 +222,8 @@ def test_ff_geglu_fused(ops, dev, M, offset):
 
 
 @pytest.mark.parametrize("M,N,ln,with_res,offset", [(32768, 320, False, True, 0.0), (32768, 960, True, False, 0.4), (24576 + 40, 320, True, True, -3.0),
-                                                     (32768, 320, False, False, 0.0), (8192 + 5, 960, False, True, 0.0)])
+                                                     (32768, 320, False, False, 0.0), (8192 + 5, 960, False, True, 0.0),
+                                                     (24576 + 77, 960, False, False, 0.0), (4096, 1920, True, False, 1.0)])
 def test_gemm_row320(ops, dev, M, N, ln, with_res, offset, monkeypatch):
     """vd_gemm_row320_f16 (rows of x resident in registers, K = 320) against torch fp32 and against gemm_f16_kernel on the same
     operands; through ops.gemm's dispatch (plain, LayerNorm-folded, with residual, ragged last row block)."""

@@ -9,7 +9,11 @@
 // no activation tile in LDS, no activation DMA, no fragment read for it -- per MFMA one ds_read_b128 of the weight tile --
 // and the [128 x 320] fp32 accumulator (80 registers) leaves through one LDS tile as 16-byte row segments (+ residual).
 // Weights stream through three 40-KiB slots ([320 rows][64 k] as two 160-row halves; requested two K tiles ahead, counted
-// vmcnt, one barrier per K tile).  N = 960 runs as three column groups (blockIdx.y), each re-reading x from L2.
+// vmcnt, one barrier per K tile).  MULTI (N = 960 and wider): ONE block walks all column groups of its rows -- x is loaded and
+// normalised once, the weight tiles of consecutive groups form one continuous stream through the slots, and a group's
+// accumulators leave through a small wave-private LDS patch (64 contiguous bytes per row and store) while the next group is
+// already being multiplied.  The single-group kernel (blockIdx.y = column group, LDS-staged 16-byte row segments +
+// residual) serves N = 320.
 #include "gemm_kernel.h"
 
 namespace {
@@ -24,7 +28,10 @@ constexpr int RG_CS_LD = RG_C + 8;
 constexpr int RG_LDS_MAIN = RG_NSLOT * RG_SLOT;
 constexpr int RG_LDS_EPI = RG_BM * RG_CS_LD * 2;
 constexpr int RG_LDS = RG_LDS_MAIN > RG_LDS_EPI ? RG_LDS_MAIN : RG_LDS_EPI;
-static_assert(RG_LDS <= 160 * 1024, "LDS budget");
+constexpr int RG_MAXBIAS = 8 * 1024;        // MULTI: the bias vector parked behind the slots (N <= 4096)
+constexpr int RG_PATCH = 32 * 80;            // MULTI: wave-private output patch [32 rows][32 columns], 80-byte pitch
+constexpr int RG_MULTI_EXTRA = RG_MAXBIAS + 8 * RG_PATCH;
+static_assert(RG_LDS + RG_MULTI_EXTRA <= 160 * 1024 && RG_LDS == RG_LDS_MAIN, "LDS budget");
 
 struct RGArgs {
     const f16* x;      // [M][320]
@@ -37,7 +44,7 @@ struct RGArgs {
     int nt_store;
 };
 
-template <bool LN>
+template <bool LN, bool MULTI>
 __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -46,10 +53,10 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * RG_BM;
-    const int n0 = blockIdx.y * RG_C;          // column group of 320
+    const int n0 = MULTI ? 0 : blockIdx.y * RG_C;   // column group of 320 (MULTI: the block walks all of them)
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const i32x4 rs_w = make_rsrc_words(p.w + (size_t)n0 * RG_C, (unsigned)(RG_C * RG_C * 2));
+    const i32x4 rs_w = make_rsrc_words(p.w + (size_t)n0 * RG_C, (unsigned)((MULTI ? p.N : RG_C) * RG_C * 2));
 
     // a 160-row half = 20 pieces of 8 rows: wave w issues pieces w, w + 8 and (w + 16 < 20 ? w + 16 : w + 8 again: identical
     // bytes to the identical place) -- every wave issues 6 pieces per K tile, so the waits can be counted
@@ -62,10 +69,10 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
         v2[j] = (unsigned)((r * RG_C + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2);
         d2[j] = (unsigned)(__builtin_amdgcn_readfirstlane(q) * 1024);
     }
-    auto issue_kt = [&](int kt, int slot) {
+    auto issue_kt = [&](int kt, int slot, int grp = 0) {   // K tile kt of column group grp
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const unsigned soff = (unsigned)((h * 160 * RG_C + kt * 64) * 2);
+            const unsigned soff = (unsigned)(((grp * RG_C + h * 160) * RG_C + kt * 64) * 2);
             const unsigned dst = lds0 + (unsigned)(slot * RG_SLOT + h * RG_HALF);
 #pragma unroll
             for (int j = 0; j < 3; ++j) dma16(rs_w, dst + d2[j], v2[j], soff);
@@ -83,6 +90,15 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
             U4H8 t;
             t.u = *reinterpret_cast<const uint4*>(xr + k * 16);
             xf[k] = t.h;
+        }
+    }
+    if constexpr (MULTI) {
+        // bias -> LDS by DMA (read with ds_read in the group epilogues: no compiler-counted global load may sit between the
+        // hand-counted requests of the loop -- hipcc would drain vmcnt, and with it the weight tiles in flight, in front of it)
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        if (p.bias && wave_s * 512 < p.N) {
+            const i32x4 rs_b = make_rsrc_words(p.bias, (unsigned)(p.N * 2));
+            dma16(rs_b, lds0 + (unsigned)(RG_LDS_MAIN + wave_s * 1024), (unsigned)(wave_s * 1024 + lane * 16), 0u);
         }
     }
     issue_kt(0, 0);
@@ -128,24 +144,94 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rd[ks] = wn * RG_HALF + lds_off_kb<64>(l31, ks * 2 + hi);   // + slot * RG_SLOT + j * 32 * 128
 
+    if constexpr (MULTI) {
+        // one continuous stream of K tiles over all column groups: tile ti = (group ti / 5, K tile ti % 5) sits in slot ti % 3,
+        // tile ti + 2 is requested right after the barrier of tile ti
+        const int ngrp = p.N / RG_C, ntile = ngrp * RG_KT;
+        int slot = 0, grp = 0;
+        for (int t0 = 0; t0 < ntile; t0 += RG_KT, ++grp) {
 #pragma unroll
-    for (int kt = 0; kt < RG_KT; ++kt) {
-        // K tile kt has landed; the tiles requested after it (kt + 1, and kt + 2 at the first step) may still be in flight
-        if (kt == 0) wait_vm<12>();
-        else if (kt + 1 < RG_KT) wait_vm<6>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();   // ... for every wave; every wave has left K tile kt - 1, whose slot is refilled now
-        asm volatile("" ::: "memory");
-        if (kt >= 1 && kt + 2 < RG_KT) issue_kt(kt + 2, (kt + 2) % RG_NSLOT);
-        const char* st = smem + (kt % RG_NSLOT) * RG_SLOT;
+            for (int kt = 0; kt < RG_KT; ++kt) {
+                const int ti = t0 + kt;
+                // tile ti has landed.  What may still be in flight behind it: tile ti + 1 (6 requests; + tile ti + 2 at the very
+                // first step), and around a group boundary the 10 output stores of the previous group's epilogue (stores count
+                // in vmcnt on gfx9): they were issued behind tile ti + 1's requests and in front of tile ti + 2's
+                if (ti == 0) wait_vm<12>();
+                else if (ti + 1 >= ntile) wait_vm<0>();
+                else if (kt <= 1 && grp > 0) wait_vm<16>();
+                else wait_vm<6>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (ti >= 1 && ti + 2 < ntile) {
+                    const int tn = ti + 2;
+                    issue_kt(tn % RG_KT, slot == 0 ? 2 : slot - 1, tn / RG_KT);   // (ti + 2) % 3: the slot tile ti - 1 has left
+                }
+                const char* st = smem + slot * RG_SLOT;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                U4H8 wf;
-                wf.u = *reinterpret_cast<const uint4*>(st + rd[ks] + j * 32 * 128);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, xf[kt * 4 + ks], acc[j], 0, 0, 0);
+                    for (int j = 0; j < 5; ++j) {
+                        U4H8 wf;
+                        wf.u = *reinterpret_cast<const uint4*>(st + rd[ks] + j * 32 * 128);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, xf[kt * 4 + ks], acc[j], 0, 0, 0);
+                    }
+                slot = slot == 2 ? 0 : slot + 1;
             }
+            // the group's accumulators leave tile by tile through a wave-private LDS patch ([32 rows][32 columns], 80-byte row
+            // pitch): + bias, fp16, then 16 bytes per lane = 64 contiguous bytes per row and store (10 stores per group: they
+            // drain while the next group is multiplied).  Rows past M were loaded from row M - 1 and store its (identical)
+            // values again: every wave issues exactly 10 stores, which the counted waits rely on.
+            {
+                char* patch = smem + RG_LDS_MAIN + RG_MAXBIAS + wave * RG_PATCH;
+                const char* bl = smem + RG_LDS_MAIN + (grp * RG_C + wn * 160 + 4 * hi) * 2;
+                const int prow = lane >> 2, pchunk = lane & 3;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        U2H4 b, o;
+                        b.u = make_uint2(0, 0);
+                        if (p.bias) b.u = *reinterpret_cast<const uint2*>(bl + (j * 32 + 8 * g) * 2);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o.e[q] = (f16)(acc[j][g * 4 + q] + (float)b.e[q]);
+                        *reinterpret_cast<uint2*>(patch + l31 * 80 + (8 * g + 4 * hi) * 2) = o.u;
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int r = prow + 16 * it;
+                        const uint4 v = *reinterpret_cast<const uint4*>(patch + r * 80 + pchunk * 16);
+                        int grow = m0 + wm * 32 + r;
+                        if (grow >= p.M) grow = p.M - 1;
+                        *reinterpret_cast<uint4*>(p.y + (size_t)grow * p.N + grp * RG_C + wn * 160 + j * 32 + pchunk * 8) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+        return;
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < RG_KT; ++kt) {
+            // K tile kt has landed; the tiles requested after it (kt + 1, and kt + 2 at the first step) may still be in flight
+            if (kt == 0) wait_vm<12>();
+            else if (kt + 1 < RG_KT) wait_vm<6>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();   // ... for every wave; every wave has left K tile kt - 1, whose slot is refilled now
+            asm volatile("" ::: "memory");
+            if (kt >= 1 && kt + 2 < RG_KT) issue_kt(kt + 2, (kt + 2) % RG_NSLOT);
+            const char* st = smem + (kt % RG_NSLOT) * RG_SLOT;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    U4H8 wf;
+                    wf.u = *reinterpret_cast<const uint4*>(st + rd[ks] + j * 32 * 128);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h, xf[kt * 4 + ks], acc[j], 0, 0, 0);
+                }
+        }
     }
     __syncthreads();   // every wave is done with the slots: the output tile re-uses that LDS
 
@@ -188,22 +274,23 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
     }
 }
 
-template <bool LN>
+template <bool LN, bool MULTI>
 int launch_rowgemm(const RGArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm320_kernel<LN>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm320_kernel<LN, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS + (MULTI ? RG_MULTI_EXTRA : 0));
         if (e != hipSuccess) {
             vd_set_error("vd_gemm_row320_f16: cannot reserve %d bytes of LDS: %s", RG_LDS, hipGetErrorString(e));
             return VD_ERR_LAUNCH;
         }
         done.fetch_or(bit, std::memory_order_release);
     }
-    const dim3 grid((unsigned)((a.M + RG_BM - 1) / RG_BM), (unsigned)(a.N / RG_C));
-    hipLaunchKernelGGL(rowgemm320_kernel<LN>, grid, dim3(512), RG_LDS, stream, a);
+    const dim3 grid((unsigned)((a.M + RG_BM - 1) / RG_BM), MULTI ? 1u : (unsigned)(a.N / RG_C));
+    constexpr int LDS = RG_LDS + (MULTI ? RG_MULTI_EXTRA : 0);
+    hipLaunchKernelGGL((rowgemm320_kernel<LN, MULTI>), grid, dim3(512), LDS, stream, a);
     return vd_check_launch("vd_gemm_row320_f16");
 }
 
@@ -224,5 +311,10 @@ extern "C" int vd_gemm_row320_f16(const void* x, const void* w, const void* bias
     a.M = (int)M; a.N = N; a.eps = ln_eps;
     static const char* nt_env = getenv("VD_GEMM_NT");
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-    return layernorm ? launch_rowgemm<true>(a, stream) : launch_rowgemm<false>(a, stream);
+    // more than one column group and no residual: one block per row block walks them all (development switch VD_ROW320_MULTI=0:
+    // one block per (row block, column group))
+    static const char* multi_env = getenv("VD_ROW320_MULTI");
+    const bool multi = N > RG_C && N <= 4096 && res == nullptr && !(multi_env && multi_env[0] == '0');
+    if (multi) return layernorm ? launch_rowgemm<true, true>(a, stream) : launch_rowgemm<false, true>(a, stream);
+    return layernorm ? launch_rowgemm<true, false>(a, stream) : launch_rowgemm<false, false>(a, stream);
 }
