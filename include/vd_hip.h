@@ -122,7 +122,7 @@ int vd_gemm_set_override(int tile_cfg);
  * tile_cfg = vd_gemm_num_configs() + variant, 0 <= variant < VD_CONV_HALO_VARIANTS (vd_gemm_config_name knows them).
  * Development hook: -1 = planner's choice (default; also the environment variable VD_CONV_HALO), 0 = never (every conv on
  * gemm_f16_kernel), k > 0 = force variant k - 1 where the geometry permits.  Process-global like vd_gemm_set_override. */
-#define VD_CONV_HALO_VARIANTS 11
+#define VD_CONV_HALO_VARIANTS 12
 int vd_conv_halo_set_variant(int setting);
 /* Tuned launch table: a problem (M, N, K, ksize, epilogue class: bit 0 GEGLU, bit 1 LayerNorm fold, bit 2 two-source A) is
  * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table

@@ -507,7 +507,7 @@ def test_conv3x3_halo_every_variant(ops, dev, case):
     try:
         for fixup in (False, True):      # channel-chunk split: slabs + reduce kernel / ticketed in-kernel reduction
             ops.HALO_FIXUP = fixup
-            for v in [-1] + list(range(0, 12)):
+            for v in [-1] + list(range(0, 13)):
                 assert lib().vd_conv_halo_set_variant(v) == 0
                 out = ops.conv2d_nhwc(x, wp, b, **kw)
                 assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, (v, fixup)

@@ -14,7 +14,7 @@ from vd_hip.loader import lib
 from vd_hip.pack import pack_conv_weight
 
 dev = torch.device("cuda:0")
-NV = 11
+NV = 12
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 
 

@@ -19,6 +19,7 @@ const HaloVariant kHalo[VD_CONV_HALO_VARIANTS] = {
     {256, 160, 512, 3, "conv3x3_halo_kernel<256,160,32,160,512,3>"},
     {256, 128, 512, 3, "conv3x3_halo_kernel<256,128,64,64,512,3>"},
     {128, 32, 256, 4, "conv3x3_halo_kernel<128,32,32,32,256,4>"},
+    {128, 160, 256, 2, "conv3x3_halo_kernel<128,160,32,160,256,2>"},
 };
 
 std::atomic<int> g_halo_variant{-2};   // -2: not read from the environment yet; -1: planner; 0: off; k > 0: force variant k - 1
@@ -121,6 +122,11 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
         if (d.N % 160 == 0) v = 2;
         else if (d.N % 128 == 0) v = 5;
         else return 0;
+        // experiment (VD_CONV_HALO128=1): where 256-pixel patches x column tiles cover less than the chip (the 32x32 and
+        // 16x16 levels: 128 / 64 tiles, split 2 / 4 over the channel chunks), 128-pixel patches on four waves double the
+        // tiles instead of the split
+        static const char* h128_env = getenv("VD_CONV_HALO128");
+        if (v == 2 && h128_env && h128_env[0] == '1' && (long)(d.M / 256) * (d.N / 160) < 256) v = 11;
     }
     const HaloVariant& hv = kHalo[v];
     ConvHaloArgs& c = *static_cast<ConvHaloArgs*>(conv_args);
@@ -189,6 +195,7 @@ int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStrea
         case 8: return launch_conv_halo<256, 160, 32, 160, 512, 3>(c, nsplit, stream);
         case 9: return launch_conv_halo<256, 128, 64, 64, 512, 3>(c, nsplit, stream);
         case 10: return launch_conv_halo<128, 32, 32, 32, 256, 4>(c, nsplit, stream);
+        case 11: return launch_conv_halo<128, 160, 32, 160, 256, 2>(c, nsplit, stream);
         default: return vd_conv_halo_launch_big(conv_args, variant, nsplit, stream);
     }
 }
