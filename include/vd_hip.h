@@ -142,6 +142,22 @@ int vd_gemm_row320_f16(const void* x, const void* w, const void* bias, const voi
                        int layernorm, float ln_eps, hipStream_t stream);
 int vd_gemm_row320_supported(int64_t M, int N, int K);
 
+/* The entry of a SpatialTransformer at inner width 320 in one launch (after the statistics): GroupNorm applied as a per-sample
+ * affine map -> proj_in -> h (the residual stream, written out), LayerNorm(h) -> fused q | k | v projection:
+ *     h = (x * scale[img] + shift[img]) W1^T + b1,     y2 = LayerNorm(h) W2^T + b2
+ * x, h: fp16 [M][320]; gn_scale / gn_shift: fp16 [M / rows_per_image][320] from vd_groupnorm_affine_f16; w1: fp16 [320][320],
+ * b1: fp16 [320]; w2: fp16 [N2][320] with the LayerNorm's gamma folded in, b2: fp16 [N2] = beta W2^T (or NULL); y2: fp16
+ * [M][N2], N2 a multiple of 320; rows_per_image a multiple of 128.  Replaces Normalize -> proj_in (lib/model_zoo/
+ * attention.py:236-258), norm1 and to_q / to_k / to_v (:214, :170-176) and this library's vd_groupnorm_silu_f16 (apply pass) ->
+ * vd_gemm_f16 -> vd_gemm_row320_f16 chain. */
+int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, const void* gn_shift, int rows_per_image, const void* w1,
+                             const void* b1, void* h, const void* w2, const void* b2, void* y2, int64_t M, int N2,
+                             float ln_eps, hipStream_t stream);
+/* GroupNorm statistics as a per-(sample, channel) affine map: scale = rstd * gamma, shift = beta - mean * scale (fp16 [B][C]),
+ * for consumers that apply the normalisation themselves.  stats: fp32 scratch of vd_groupnorm_workspace_bytes(). */
+int vd_groupnorm_affine_f16(const void* x, const void* gamma, const void* beta, void* scale, void* shift, float* stats, int B,
+                            int HW, int C, int groups, float eps, hipStream_t stream);
+
 /* The gated feed-forward of a BasicTransformerBlock in one launch (inner width C = 320 only: vd_ff_geglu_supported):
  *     y[m] = res[m] + ( v (*) gelu_erf(g) ) W2^T + b2,     [v | g] = LayerNorm(x[m]) W1^T + b1
  * x, res, y: fp16 [M][C]; w1_packed: fp16 [8C][C] with LayerNorm's gamma folded in (W1 * gamma) and rows packed per 64 as

@@ -258,6 +258,37 @@ def test_gemm_row320(ops, dev, M, N, ln, with_res, offset, monkeypatch):
     assert rel_l2(out, old.float()) < 3e-3
 
 
+@pytest.mark.parametrize("B,HW,offset", [(8, 4096, 0.0), (7, 4096, 0.7), (2, 9216, -2.0), (25, 1024, 0.0)])
+def test_row320_chain(ops, dev, B, HW, offset):
+    """vd_groupnorm_affine_f16 + vd_gemm_row320_chain_f16 (GroupNorm as an affine map -> proj_in -> h; LayerNorm(h) -> q|k|v in
+    one launch) against torch fp32, and h / q|k|v against the library's separate launches."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    C = 320
+    x = rnd((B, HW, C), dev, 1.3, 950) + offset + 0.5 * rnd((1, 1, C), dev, 1.0, 951)
+    gam, bet = 1.0 + 0.2 * rnd((C,), dev, 1.0, 952), 0.1 * rnd((C,), dev, 1.0, 953)
+    w1, b1 = rnd((C, C), dev, C ** -0.5, 954), rnd((C,), dev, 0.2, 955)
+    w2 = rnd((3 * C, C), dev, C ** -0.5, 956)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(957)).to(dev))
+        ln.bias.copy_(0.1 * torch.randn(C, generator=torch.Generator().manual_seed(958)).to(dev))
+    xn = F.group_norm(x.float().transpose(1, 2), 32, gam.float(), bet.float(), 1e-6).transpose(1, 2)
+    h_ref = xn @ w1.float().t() + b1.float()
+    y_ref = F.layer_norm(h_ref, (C,), ln.weight.float(), ln.bias.float(), 1e-5) @ w2.float().t()
+    sc, sh = ops.groupnorm_affine(x, gam, bet, groups=32, eps=1e-6)
+    mean = x.float().view(B, HW, 32, C // 32).mean((1, 3))
+    var = x.float().view(B, HW, 32, C // 32).var((1, 3), unbiased=False)
+    sc_ref = (var + 1e-6).rsqrt().repeat_interleave(C // 32, 1) * gam.float()
+    assert rel_l2(sc, sc_ref) < 2e-3 and rel_l2(sh, bet.float() - mean.repeat_interleave(C // 32, 1) * sc_ref) < 3e-3
+    w2p, b2p, cs = fold_layernorm(w2, None, ln)
+    h, y = ops.row320_chain(x, sc, sh, HW, w1, b1, w2p, b2p, 1e-5)
+    assert h.shape == (B, HW, C) and y.shape == (B, HW, 3 * C)
+    assert rel_l2(h, h_ref) < 3e-3 and rel_l2(y, y_ref) < 4e-3
+    hs = ops.linear(ops.groupnorm_silu(x, gam, bet, groups=32, eps=1e-6, silu=False), w1, b1)
+    ys = ops.linear(hs, w2p, b2p, colsum=cs, ln_eps=1e-5)
+    assert rel_l2(h, hs.float()) < 3e-3 and rel_l2(y, ys.float()) < 4e-3
+
+
 @pytest.mark.parametrize("B,H,D,Nq,Nk,offset", [
     (2, 8, 40, 1024, 77, 0.0), (8, 8, 40, 4096, 77, 0.3), (1, 8, 40, 200, 77, -1.5), (2, 8, 80, 256, 257, 0.0),
     (8, 8, 80, 1024, 77, 2.0), (2, 8, 160, 64, 514, 0.0), (3, 8, 160, 100, 77, 0.5), (8, 8, 160, 256, 77, 0.0),

@@ -486,6 +486,71 @@ extern "C" int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int
     return vd_check_launch("vd_groupnorm_silu_f16");
 }
 
+namespace {
+// GroupNorm as a per-(sample, channel) affine map: scale = rstd * gamma, shift = beta - mean * scale (fp16), from the slab
+// partial sums of gn_partial_kernel -- for consumers that apply the normalisation themselves (vd_gemm_row320_chain_f16).
+__global__ __launch_bounds__(256) void gn_affine_kernel(const f16* x0, const f16* gamma, const f16* beta, const float* part,
+                                                        f16* sc, f16* sh, int HW, int C, int groups, int nchunk,
+                                                        float inv_count, float eps) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    __shared__ float red[256];
+    __shared__ float stat[64 * 2];
+    const int ne = groups * 2;
+    const int e = tid % ne, lanes = 256 / ne, cl = tid / ne;
+    float acc = 0.f;
+    if (cl < lanes) {
+        const float* pp = part + (size_t)b * nchunk * ne + e;
+        int c = cl;
+        for (; c + 7 * lanes < nchunk; c += 8 * lanes) {  // 8 independent loads in flight: this is a latency chain
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pp[(size_t)(c + u * lanes) * ne];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; c < nchunk; c += lanes) acc += pp[(size_t)c * ne];
+    }
+    red[tid] = (cl < lanes) ? acc : 0.f;
+    __syncthreads();
+    if (tid < ne) {
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += red[l * ne + tid];
+        red[tid] = t;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const float ms = red[tid * 2] * inv_count;   // mean of (x - k)
+        float var = red[tid * 2 + 1] * inv_count - ms * ms;
+        if (var < 0.f) var = 0.f;
+        stat[tid * 2] = ms + (float)x0[(size_t)b * HW * C + tid * (C / groups)];   // the group's shift k_g (gn_shift)
+        stat[tid * 2 + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int cg = C / groups;
+    for (int c = tid; c < C; c += 256) {
+        const float mean = stat[(c / cg) * 2], rstd = stat[(c / cg) * 2 + 1];
+        const float s = rstd * (float)gamma[c];
+        sc[(size_t)b * C + c] = (f16)s;
+        sh[(size_t)b * C + c] = (f16)((float)beta[c] - mean * s);
+    }
+}
+}  // namespace
+
+extern "C" int vd_groupnorm_affine_f16(const void* x, const void* gamma, const void* beta, void* scale, void* shift,
+                                       float* stats, int B, int HW, int C, int groups, float eps, hipStream_t stream) {
+    VD_REQUIRE(x && gamma && beta && scale && shift && stats, "vd_groupnorm_affine_f16: null pointer");
+    VD_REQUIRE(B > 0 && HW > 0 && C > 0, "vd_groupnorm_affine_f16: empty input");
+    VD_REQUIRE(groups > 0 && groups <= 64 && C % groups == 0 && C % 8 == 0 && C <= GN_MAX_POS * 256 * 8,
+               "vd_groupnorm_affine_f16: bad groups=%d / C=%d", groups, C);
+    const GnGeom g = gn_geom(HW, C);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(g.nchunk, B), dim3(256), 0, stream, (const f16*)x, C, (const f16*)nullptr, 0,
+                       stats, HW, groups, g);
+    hipLaunchKernelGGL(gn_affine_kernel, dim3(B), dim3(256), 0, stream, (const f16*)x, (const f16*)gamma, (const f16*)beta,
+                       (const float*)stats, (f16*)scale, (f16*)shift, HW, C, groups, g.nchunk,
+                       1.0f / ((float)HW * (float)(C / groups)), eps);
+    return vd_check_launch("vd_groupnorm_affine_f16");
+}
+
 extern "C" int vd_groupnorm0d_silu_f16(const void* x0, int c0, const void* x1, int c1, const void* gamma, const void* beta,
                                        void* y, int B, int S, int groups, float eps, int apply_silu, hipStream_t stream) {
     if (x1 == nullptr) c1 = 0;

@@ -100,12 +100,15 @@ class CrossAttention(nn.Module, PackCache):
         return self._packed("q_ln", (self.to_q.weight, ln.weight, ln.bias),
                             lambda: fold_layernorm(_h(self.to_q.weight), None, ln))
 
-    def forward(self, x, context=None, res=None, kv=None, ln=None):
+    def forward(self, x, context=None, res=None, kv=None, ln=None, qkv=None):
         """x [B, N, C] -> to_out(attn) (+ res fused).  ln: the LayerNorm in front of the block's q (and self k / v)
-        projections, folded into them -- x is then the un-normalised input."""
+        projections, folded into them -- x is then the un-normalised input.  qkv: the fused self-attention projection when
+        the caller has already computed it (SpatialTransformer's chained entry kernel)."""
         c = self.inner
         if context is None and kv is None:
-            if ln is None:
+            if qkv is not None:
+                pass
+            elif ln is None:
                 qkv = ops.linear(x, self._w_qkv())
             else:
                 w, b, cs = self._w_qkv_ln(ln)
@@ -141,9 +144,9 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
 
-    def forward(self, x, context=None, kv=None):
+    def forward(self, x, context=None, kv=None, qkv=None):
         if hip_layers.LN_FOLD:  # the three LayerNorms ride in the q/k/v, q and GEGLU projections (VD_EPI_LNFOLD)
-            x = self.attn1(x, res=x, ln=self.norm1)
+            x = self.attn1(x, res=x, ln=self.norm1, qkv=qkv)
             x = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2)
             return self.ff(x, res=x, ln=self.norm3)
         x = self.attn1(self.norm1(x), res=x)
@@ -177,6 +180,17 @@ class SpatialTransformer(nn.Module):
         """Returns alpha * (proj_out(...) + bias) + res, res defaulting to x (the block's own skip).
         alpha/res implement VD's context mixing sum_i r_i * ST_i(x) without extra passes."""
         B, H, W, C = x.shape
+        blk = self.transformer_blocks[0]
+        inner = self.proj_in.out_channels
+        if hip_layers.LN_FOLD and x.is_contiguous() and ops.st_chain_supported(B, H * W, C, inner):
+            # GroupNorm (as a per-sample affine map) -> proj_in -> h and LayerNorm(h) -> q | k | v in one launch
+            g, b = self.norm._w()
+            sc, sh = ops.groupnorm_affine(x, g, b, groups=self.norm.num_groups, eps=self.norm.eps)
+            w1, b1 = self.proj_in._w()
+            w2, b2, _ = blk.attn1._w_qkv_ln(blk.norm1)
+            h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps)
+            h = blk(h, context=context, kv=kv, qkv=qkv)
+            return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res)
         h = self.proj_in(self.norm(x, silu=False))
         h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv)
         return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res)

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "vd_ff_geglu_supported": (_I, [_I]),
     "vd_gemm_row320_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "vd_gemm_row320_supported": (_I, [_L, _I, _I]),
+    "vd_gemm_row320_chain_f16": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "vd_groupnorm_affine_f16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "vd_gemm_tune_set": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vd_gemm_tune_clear": (_I, []),
     "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),

@@ -289,6 +289,47 @@ def gemm_row320(a0, w, bias=None, res=None, layernorm=False, ln_eps=1e-5, out_sh
     return out
 
 
+# opt-in (VD_ST_CHAIN=1): GroupNorm (as an affine map) -> proj_in -> LayerNorm -> q|k|v of a 64x64-level SpatialTransformer in one
+# launch + a statistics launch.  Correct (test_row320_chain), measured neutral: 54 + 18 us against 23 + 24 + 39 us for the three
+# launches it replaces, forward 11.18 vs 11.21 ms (tools/gpu_r03_ad.sh).
+ST_CHAIN = os.environ.get("VD_ST_CHAIN", "0") == "1"
+
+
+def st_chain_supported(B, HW, C, inner):
+    """True when vd_gemm_row320_chain_f16 can take the entry of a SpatialTransformer (width 320, row blocks fill the chip)."""
+    return ST_CHAIN and ROW320 and C == 320 and inner == 320 and HW % 128 == 0 and B * HW // 128 >= 192
+
+
+def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5):
+    """GroupNorm of channels-last x [B, ..., C] as a per-(sample, channel) affine map -> (scale, shift) fp16 [B, C]."""
+    _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    sc = torch.empty((B, C), dtype=torch.float16, device=x.device)
+    sh = torch.empty((B, C), dtype=torch.float16, device=x.device)
+    ws = workspace(lib().vd_groupnorm_workspace_bytes(B, HW, C, groups), x.device, "gn")
+    with _Timed("groupnorm statistics -> affine", 0.0, 2.0 * B * HW * C):
+        _check(lib().vd_groupnorm_affine_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(sc), _ptr(sh), _ptr(ws), B, HW, C, groups,
+                                             float(eps), _stream()))
+    return sc, sh
+
+
+def row320_chain(x, sc, sh, rows_per_image, w1, b1, w2, b2, ln_eps):
+    """h = (x * sc[img] + sh[img]) @ w1^T + b1;  y2 = LayerNorm(h) @ w2^T + b2 (w2 / b2 LayerNorm-folded) in one launch
+    (vd_gemm_row320_chain_f16).  x [..., 320] contiguous -> (h [..., 320], y2 [..., N2])."""
+    for t, n in ((x, "x"), (sc, "sc"), (sh, "sh"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        _req(t, n)
+    M = x.numel() // 320
+    N2 = w2.shape[0]
+    h = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    y2 = torch.empty(x.shape[:-1] + (N2,), dtype=torch.float16, device=x.device)
+    name = "rowchain320_kernel" + ((" M=%d N2=%d" % (M, N2)) if PROFILE_SHAPES else "")
+    with _Timed(name, 2.0 * M * 320 * (320 + N2), 2.0 * (2 * M * 320 + M * N2 + 320 * (320 + N2))):
+        _check(lib().vd_gemm_row320_chain_f16(_ptr(x), _ptr(sc), _ptr(sh), int(rows_per_image), _ptr(w1), _ptr(b1), _ptr(h),
+                                              _ptr(w2), _ptr(b2), _ptr(y2), M, N2, float(ln_eps), _stream()))
+    return h, y2
+
+
 LN_INLOOP = os.environ.get("VD_LN_INLOOP", "0") == "1"   # 1 = LN statistics inside the K loop of the folded GEMM (measured neutral: +3..7 us per GEMM = the vd_row_stats_f16 launches it removes; the two-pass statistics stay the default)
 FF_FUSED = os.environ.get("VD_FF_FUSED", "1") != "0"   # development switch: 0 = always the three-launch chain
 
@@ -708,7 +749,7 @@ def _guarded(fn):
     return wrapper
 
 
-for _name in ("gemm", "gemm_row320", "ff_geglu", "xattn", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
+for _name in ("gemm", "gemm_row320", "row320_chain", "groupnorm_affine", "ff_geglu", "xattn", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
               "unary", "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
