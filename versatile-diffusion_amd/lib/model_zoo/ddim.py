@@ -9,6 +9,7 @@ and -- because every launch goes to torch's current stream with static shapes --
 only refreshes a 6-float coefficient vector and the timestep tensor.  Set VD_DDIM_GRAPH=0 to run every step eagerly.
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -27,6 +28,9 @@ class DDIMSampler(object):
         self.use_graph = os.environ.get("VD_DDIM_GRAPH", "1") != "0"
         self.graph_cache = os.environ.get("VD_DDIM_GRAPH_CACHE", "1") != "0"   # keep captured steps across sample() calls
         self._static = {}
+        # one request at a time per sampler: the kept step graphs read and write static buffers (the reference's sampler is
+        # not re-entrant either, but it has no captured state to corrupt; app.py runs Gradio workers unlocked)
+        self._lock = threading.RLock()
 
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
@@ -34,8 +38,9 @@ class DDIMSampler(object):
     def release_graphs(self):
         """Drop the kept step graphs with their static latent / context / K-V buffers and private memory pools (up to two
         geometries are kept alive per sampler; at 768x768, batch 32 that is a sizeable HBM reservation).  The next
-        sample() call captures again.  Not re-entrant: one sampler serves one request at a time (like the reference's)."""
-        self._static.clear()
+        sample() call captures again.  Serialised with running sample() calls by the sampler's lock."""
+        with self._lock:
+            self._static.clear()
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
         self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
@@ -58,11 +63,12 @@ class DDIMSampler(object):
     @torch.no_grad()
     def sample(self, steps, shape, x_info, c_info, eta=0., temperature=1., noise_dropout=0., verbose=True,
                log_every_t=100):
-        self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
-        if verbose:
-            print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
-        return self.ddim_sampling_multicontext(shape, x_info, [c_info], noise_dropout=noise_dropout,
-                                               temperature=temperature, log_every_t=log_every_t, _single=True)
+        with self._lock:   # the schedule attributes and the kept step graphs are per-sampler state
+            self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
+            if verbose:
+                print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
+            return self.ddim_sampling_multicontext(shape, x_info, [c_info], noise_dropout=noise_dropout,
+                                                   temperature=temperature, log_every_t=log_every_t, _single=True)
 
     @torch.no_grad()
     def ddim_sampling(self, shape, x_info, c_info, noise_dropout=0., temperature=1., log_every_t=100):
@@ -73,15 +79,20 @@ class DDIMSampler(object):
     @torch.no_grad()
     def sample_multicontext(self, steps, shape, x_info, c_info_list, eta=0., temperature=1., noise_dropout=0.,
                             verbose=True, log_every_t=100):
-        self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
-        if verbose:
-            print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
-        return self.ddim_sampling_multicontext(shape, x_info, c_info_list, noise_dropout=noise_dropout,
-                                               temperature=temperature, log_every_t=log_every_t)
+        with self._lock:
+            self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
+            if verbose:
+                print("Data shape for DDIM sampling is {}, eta {}".format(shape, eta))
+            return self.ddim_sampling_multicontext(shape, x_info, c_info_list, noise_dropout=noise_dropout,
+                                                   temperature=temperature, log_every_t=log_every_t)
 
     @torch.no_grad()
     def ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout=0., temperature=1.,
                                    log_every_t=100, _single=False):
+        with self._lock:
+            return self._ddim_sampling_multicontext(shape, x_info, c_info_list, noise_dropout, temperature, log_every_t, _single)
+
+    def _ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout, temperature, log_every_t, _single):
         assert noise_dropout == 0., "noise_dropout is a training-time option"
         device = self.model.device
         dtype = c_info_list[0]["conditioning"].dtype
