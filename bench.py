@@ -4,6 +4,8 @@
     python bench.py --gpus N --steps K --warmup W [--workload t2i|i2v|dual|triple]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+(`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under torch.distributed.run with N
+ranks, or exits non-zero when the node has fewer than N GPUs -- it never reports n_gpus: 1 for a --gpus N request.)
 
 One "step" = one pass of the hot path over one batch: a guided (CFG 7.5) 50-step DDIM loop over the batch's latents,
 followed by the KL-f8 decode.  The default workload is BASELINE.json configs[1] ("text-to-image 512x512, 50 DDIM steps,
@@ -20,6 +22,8 @@ The JSON line also carries
   roofline      -- for the kernel that dominates a UNet forward of the workload: algorithmic FLOPs of its launches /
                    their measured duration (events on the launch stream), against the dense fp16 MFMA peak of MI355X
   cpu_baseline  -- the CPU fp32 oracle (oracle/vd_oracle.py, kind "port") timed on this host on a bounded sample
+  other_workloads -- (default t2i run at N = 1 only) BASELINE configs[2..4] through the same code path, 1 warm-up + 2 timed
+                   batches each, OUTSIDE the timed region of the headline value: images/s and ms per batch per workload
 """
 import argparse
 import json
@@ -252,6 +256,53 @@ def cpu_baseline_leg(net, device):
                       "decode 32x32 latent x4 area = %.2f s; extrapolated 50*forward + decode per image" % (cores, t_fwd, t_dec)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: re-run this command as N ranks under torch.distributed.run."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node has %d visible GPU(s); refusing to report a %d-GPU number from fewer "
+                         "devices" % (n, have, n))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def timed_batches(net, sampler, wl, ctxs, n_global, ddim_steps, images, warmup, steps, barrier):
+    """`warmup` untimed + `steps` timed batches of one workload; returns (seconds, last images)."""
+    img = None
+    for i in range(warmup):
+        img = one_batch(net, sampler, wl, ctxs, n_global, ddim_steps, i, images)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        img = one_batch(net, sampler, wl, ctxs, n_global, ddim_steps, 10 + i, images)
+    barrier()
+    return time.perf_counter() - t0, img
+
+
+def workload_inputs(wl, per_gpu, world, rank, device):
+    n_global = per_gpu * world
+    ctxs = make_contexts(wl, n_global, device, 1000)   # same seed on every rank: the full batch, sliced per rank
+    images = None
+    if wl["vae_enc"]:
+        lo = per_gpu * rank
+        gi = torch.Generator(device=device).manual_seed(2000)
+        images = torch.rand((n_global, 3, 8 * wl["side"], 8 * wl["side"]), generator=gi, device=device).half()[lo:lo + per_gpu]
+    return n_global, ctxs, images
+
+
+def default_per_gpu(wl):
+    # t2i / i2v: BASELINE quotes a per-GPU batch.  dual / triple: BASELINE quotes the GLOBAL batch of the 8-GPU job (16 / 32);
+    # a rank always runs its share of that job (2 / 4 images), so on N GPUs the job is N/8 of the 8-GPU one: per-GPU work is
+    # fixed as N grows = weak scaling for every workload
+    return max(1, wl["batch"] // 8) if wl["global_fixed"] else wl["batch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,13 +314,19 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the other_workloads block (configs[2..4], 2 timed batches each) of the default t2i line")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="run only the cpu_baseline leg (VD_CPU_THREADS selects the pinned thread count) and print it")
     ap.add_argument("--dump-kernel-table", default=None, help="write the per-kernel table of the roofline leg here")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
@@ -281,18 +338,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
-    assert world == args.gpus or not distributed, "launch with --nproc-per-node == --gpus"
 
-    # batch: t2i / i2v keep the per-GPU batch fixed (weak scaling: N GPUs sample N x batch images per step);
-    # dual / triple have BASELINE's GLOBAL batch (16 / 32) sharded over the ranks (strong scaling); on fewer than 8 GPUs
-    # they run the per-GPU share of the 8-GPU configuration (2 / 4 per GPU) unless --batch says otherwise
-    if args.batch is not None:
-        per_gpu = args.batch
-    elif wl["global_fixed"]:
-        per_gpu = max(1, wl["batch"] // 8)
-    else:
-        per_gpu = wl["batch"]
-    n_global = per_gpu * world
+    # per-GPU batch fixed for every workload (see default_per_gpu): N GPUs sample N x per_gpu images per step
+    per_gpu = args.batch if args.batch is not None else default_per_gpu(wl)
     scaling = "weak"
 
     from lib.model_zoo.ddim import DDIMSampler
@@ -301,27 +349,14 @@ def main():
         print(json.dumps({"cpu_baseline": cpu_baseline_leg(net, device)}))
         return
     sampler = DDIMSampler(net)
-    ctxs = make_contexts(wl, n_global, device, 1000)   # same seed on every rank: the full batch, sliced per rank
-    images = None
-    if wl["vae_enc"]:
-        lo = per_gpu * rank
-        gi = torch.Generator(device=device).manual_seed(2000)
-        images = torch.rand((n_global, 3, 8 * wl["side"], 8 * wl["side"]), generator=gi, device=device).half()[lo:lo + per_gpu]
+    n_global, ctxs, images = workload_inputs(wl, per_gpu, world, rank, device)
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    img = None
-    for i in range(args.warmup):
-        img = one_batch(net, sampler, wl, ctxs, n_global, args.ddim_steps, i, images)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        img = one_batch(net, sampler, wl, ctxs, n_global, args.ddim_steps, 10 + i, images)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, img = timed_batches(net, sampler, wl, ctxs, n_global, args.ddim_steps, images, args.warmup, args.steps, barrier)
     if distributed:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -365,6 +400,29 @@ def main():
                     json.dump(table, f, indent=1, sort_keys=True)
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_leg(net, device)
+    if world == 1 and args.workload == "t2i" and args.batch is None and not args.no_other_workloads:
+        # BASELINE configs[2..4] on this GPU, after (and outside) the headline's timed region: the driver only ever runs the
+        # default command, this block gives those configurations a driver-run number as well
+        others = {}
+        del ctxs, images, img
+        for name in ("i2v", "dual", "triple"):
+            w2 = WORKLOADS[name]
+            sampler.release_graphs()
+            torch.cuda.empty_cache()
+            pg = default_per_gpu(w2)
+            ng, c2, im2 = workload_inputs(w2, pg, world, rank, device)
+            sec, im = timed_batches(net, sampler, w2, c2, ng, args.ddim_steps, im2, 1, 2, barrier)
+            px2 = 8 * w2["side"]
+            assert im.shape == (ng, 3, px2, px2) and bool(torch.isfinite(im).all())
+            nst = int(args.ddim_steps * (1 - FIDELITY)) if w2["vae_enc"] else args.ddim_steps
+            tf = pg * (2 * nst * w2["gf_fwd"] + w2["vae_dec"] + w2["vae_enc"]) / 1e3
+            others[name] = {"config": "BASELINE configs[%d]: %s" % (w2["cfg"], w2["desc"]), "value": round(ng * 2 / sec, 4),
+                            "unit": "images/s", "metric": "%dx%d images/sec (50-step DDIM)" % (px2, px2), "n_gpus": world,
+                            "bs_per_gpu": pg, "steps": 2, "warmup": 1, "ms_per_step": round(1e3 * sec / 2, 2), "scaling": "weak",
+                            "whole_path_frac_of_mfma_peak": round(tf / (sec / 2) / MFMA_FP16_PEAK_TFLOPS, 4)}
+            del c2, im2, im
+        out["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(out))
     if distributed:
         dist.barrier()

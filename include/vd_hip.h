@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 4
+#define VD_HIP_ABI_VERSION 5
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -45,6 +45,7 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
 #define VD_EPI_BIAS_ALONG_M 8 /* bias indexed by output row (V^T = Wv x^T in the VAE AttnBlock) */
 #define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
 #define VD_EPI_LNFOLD 32      /* A rows are LayerNorm'ed on the fly, see VdGemmDesc.colsum     */
+#define VD_EPI_LN_INLOOP 64   /* with VD_EPI_LNFOLD and ln_stats == NULL: row statistics inside the K loop (explicit opt-in) */
 
 #define VD_ACT_NONE 0
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
@@ -59,11 +60,12 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
  *    LN(a)[m][k] = (a[m][k] - mean_m) * rstd_m * gamma[k] + beta[k]
  *    sum_k LN(a)[m][k] W[n][k] = rstd_m * ( sum_k a[m][k] W'[n][k] - mean_m * colsum[n] ) + bias'[n]
  * with W' = gamma (*) W (passed as `w`), colsum[n] = sum_k W'[n][k] (fp32) and bias' = beta W^T + bias (passed as `bias`),
- * all prepared once per layer by the host.  (mean_m, rstd_m): with `ln_stats` == NULL the kernel accumulates sum and sum
- * of squares of every A row from the operand fragments inside its K loop (biased variance, `ln_eps`), so the nn.LayerNorm in
- * front of a projection (lib/model_zoo/attention.py:214-218) costs no pass over memory and no launch; otherwise they are
- * read from `ln_stats` (vd_row_stats_f16: two-pass statistics, one extra read of A).  Plain (non-conv, single-source) A
- * only, no split-K.
+ * all prepared once per layer by the host.  (mean_m, rstd_m) are read from `ln_stats` (vd_row_stats_f16: two-pass
+ * statistics, one extra read of A).  With VD_EPI_LN_INLOOP and `ln_stats` == NULL the kernel instead accumulates sum and sum
+ * of squares of every A row from the operand fragments inside its K loop (biased variance, `ln_eps`; one-pass E[x^2] - mean^2
+ * on the raw fp16 values, less robust for |mean| >> std, hence opt-in: a NULL `ln_stats` without the flag is an error), so
+ * the nn.LayerNorm in front of a projection (lib/model_zoo/attention.py:214-218) costs no pass over memory and no launch.
+ * Plain (non-conv, single-source) A only, no split-K.
  * A[m][k] is gathered on the fly: m -> (b, oy, ox) over Hout x Wout, k -> (ky, kx, c) with c running
  * over the channels of a0 (c0) then a1 (c1) -- i.e. torch.cat([a0, a1], dim=1) is never materialised --
  * at input pixel ((oy*stride - pad + ky) >> ups, (ox*stride - pad + kx) >> ups) (ups=1: nearest 2x upsample
@@ -94,8 +96,14 @@ typedef struct VdGemmDesc {
                           * private to the stream (launches on one stream are ordered; the kernel leaves them zero).  With
                           * them the last-arriving block of each output tile sums the tile's fp32 slabs (in split order:
                           * results stay run-to-run identical) and runs the fused epilogue itself -- no reduce launch.   */
-    const float* ln_stats; /* VD_EPI_LNFOLD: NULL (statistics inside the K loop) or fp32 [batch*M][2] = (mean, rstd) of
-                            * every A row from vd_row_stats_f16                                                     */
+    const float* ln_stats; /* VD_EPI_LNFOLD: fp32 [batch*M][2] = (mean, rstd) of every A row from vd_row_stats_f16 (NULL only
+                            * with VD_EPI_LN_INLOOP)                                                                */
+    float* out_stats;      /* optional (ABI 5): per-channel statistics of the STORED output for a consuming GroupNorm, fp32
+                            * [M / R][N][2] = (mean, M2 = sum (x - mean)^2) over blocks of R rows of one image; R =
+                            * vd_gemm_stat_rows(desc) (depends on the launch the planner picks; 0 = this launch cannot emit
+                            * them: leave out_stats NULL and use vd_chan_stats_f16).  fp16 output, batch 1, N % 8 == 0.     */
+    int32_t stat_img_rows; /* rows of one image for out_stats (partials never mix images); 0 = Hout * Wout (M for plain matrices) */
+    int32_t reserved2;
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -109,6 +117,10 @@ size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
 /* Dry run of the launch planner: tile_cfg indexes the instantiation table of vd_gemm_config_name(); nsplit = split-K
  * factor.  Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
 int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
+/* Rows per statistics partial the launch planned for `desc` would write to desc->out_stats (the pointer itself is not
+ * read): the halo-resident convolution emits one partial per 256-pixel patch (or per whole small image), gemm_f16_kernel one
+ * per min(tile rows, image rows), the split-K reduce one per 64 rows.  *rows = 0: no statistics from this launch. */
+int vd_gemm_stat_rows(const VdGemmDesc* desc, int* rows);
 /* "gemm_f16_kernel<BM,BN,WM,WN,NT,STAGES,KB>" of tile_cfg (NULL when out of range); vd_gemm_num_configs() entries. */
 const char* vd_gemm_config_name(int tile_cfg);
 int vd_gemm_num_configs(void);
@@ -177,6 +189,28 @@ int vd_groupnorm_silu_f16(const void* x0, int c0, const void* x1, int c1, const 
                           void* y, float* stats, int B, int HW, int groups, float eps, int apply_silu,
                           hipStream_t stream);
 size_t vd_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+
+/* ---- GroupNorm without its own statistics pass (ABI 5, csrc/gn_fused.hip) ----------------------------------------------
+ * The producer of a tensor emits per-channel partial statistics while it stores it (VdGemmDesc.out_stats): fp32
+ * [B * T][C][2] = (mean, M2 = sum (x - mean)^2) over T blocks of HW / T rows per sample.  Per channel, so the consumer folds
+ * the channels of one tensor, or of both tensors of a skip concat (vd.py:371), into its groups whatever the producers' tile
+ * shapes were, and a tensor consumed twice (every skip connection) is measured once.
+ * vd_groupnorm_from_stats_f16: y = GroupNorm(cat(x0, x1)) [+ SiLU] in ONE launch that reads x once -- each block folds the
+ *   partials of its groups (Chan's parallel variance update, fp32) and streams its panel.  Same contract as
+ *   vd_groupnorm_silu_f16 otherwise; replaces GroupNorm32 + SiLU / Normalize at the same reference lines.
+ * vd_chan_stats_f16: the same partials computed with one read of x [M][C] (row stride ldx), one per rows_per_partial
+ *   consecutive rows (a divisor of the sample's row count): for tensors whose producer cannot emit them, and the reference
+ *   the producers are tested against.
+ * vd_gn_table_f32: partials -> the normalisation as a per-(sample, channel) affine map, fp32 table [B][2][C0 + C1]:
+ *   scale = rstd * gamma, shift = beta - mean * scale;  vd_gn_apply_table_f16: y = act(x * scale + shift), elementwise. */
+int vd_groupnorm_from_stats_f16(const void* x0, int c0, const float* stats0, int T0, const void* x1, int c1,
+                                const float* stats1, int T1, const void* gamma, const void* beta, void* y, int B, int HW,
+                                int groups, float eps, int apply_silu, hipStream_t stream);
+int vd_chan_stats_f16(const void* x, long M, int C, int ldx, int rows_per_partial, float* stats, hipStream_t stream);
+int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
+                    const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream);
+int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int apply_silu,
+                          void* y, hipStream_t stream);
 
 /* GroupNorm(groups) [+ SiLU] of the 0-D (text-latent) data flow: FCBlock normalises the flattened [C, sdim] vector of a
  * sample with one affine pair per flat element (reference openaimodel.py:2084-2141 with the [C, sdim, 1] -> C*sdim view

@@ -141,3 +141,46 @@ def test_tuned_entry_with_split_is_honoured_on_the_relaunch():
         assert ns.value == 2
     finally:
         lib().vd_gemm_tune_clear()
+
+
+def stat_rows(M, N, K, ks=1, B=8, ws=True, flags=0, act=0, img_rows=0, conv1x1=False, sync=False, colsum=False):
+    from vd_hip.loader import VdGemmDesc, lib
+    assert lib().vd_conv_halo_set_variant(-1) == 0
+    d = VdGemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a0 = d.w = d.out = 16
+    if ks == 3 or conv1x1:
+        h = int(round((M // B) ** 0.5))
+        d.Hin = d.Win = d.Hout = d.Wout = h
+        d.ksize, d.stride, d.pad, d.c0 = (3, 1, 1, K // 9) if ks == 3 else (1, 1, 0, K)
+    d.act, d.flags, d.stat_img_rows = act, flags, img_rows
+    d.ws = 16 if ws else None
+    d.sync = 16 if sync else None
+    if colsum:
+        d.colsum = d.ln_stats = 16
+    rows = ctypes.c_int(-1)
+    assert lib().vd_gemm_stat_rows(ctypes.byref(d), ctypes.byref(rows)) == 0
+    return rows.value
+
+
+def test_which_launches_emit_groupnorm_statistics():
+    """vd_gemm_stat_rows: rows per out_stats partial of the launch the planner picks (round 4, csrc/gn_fused.hip)."""
+    # halo conv, one block per 256-pixel patch: the epilogue emits one partial per patch
+    assert stat_rows(32768, 320, 2880, ks=3) == 256
+    # 32x32 / 16x16 / 8x8 levels run split over K: the reduce kernel emits one partial per 64 rows
+    assert stat_rows(8192, 640, 5760, ks=3) == 64
+    assert stat_rows(2048, 1280, 11520, ks=3) == 64
+    assert stat_rows(512, 1280, 11520, ks=3) == 64
+    # ... but not through the in-kernel fix-up (ticket counters supplied)
+    assert stat_rows(2048, 1280, 11520, ks=3, sync=True) == 0
+    # SpatialTransformer.proj_out: 1x1 conv on gemm_f16_kernel, one partial per tile (128 rows), or per image where a
+    # tile spans several 8x8 images
+    assert stat_rows(32768, 320, 320, conv1x1=True) == 128
+    assert stat_rows(512, 1280, 1280, conv1x1=True) == 64
+    # plain matrices need the rows of one sample; without it the whole matrix is one "image"
+    assert stat_rows(32768, 320, 64, img_rows=4096) in (64, 128)
+    assert stat_rows(32768, 320, 64) in (64, 128)
+    # GEGLU / fp32 output / LayerNorm-fold launches never feed a GroupNorm
+    assert stat_rows(8192, 5120, 640, act=1) == 0
+    assert stat_rows(8192, 640, 640, flags=16) == 0
+    assert stat_rows(8192, 1920, 640, flags=32, colsum=True) == 0

@@ -24,7 +24,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(PROTOTYPES), (declared ^ set(PROTOTYPES))
     for name in declared:
         assert hasattr(h, name), name
-    assert h.vd_abi_version() == 4
+    assert h.vd_abi_version() == 5
     # argument validation works without a device
     from vd_hip.loader import VdGemmDesc
     d = VdGemmDesc()
@@ -35,11 +35,12 @@ def test_capi_exports_every_declared_symbol():
 
 def test_gemm_desc_struct_matches_header():
     from vd_hip.loader import VdGemmDesc
-    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8
+    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4
     assert VdGemmDesc.stride_a.offset == 8 * 8 + 24 * 4
     assert VdGemmDesc.colsum.offset == 8 * 8 + 24 * 4 + 4 * 8   # LayerNorm-fold fields (ABI 2)
-    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 16   # split-K arrival counters (ABI 2)
-    assert VdGemmDesc.ln_stats.offset == ctypes.sizeof(VdGemmDesc) - 8   # LayerNorm-fold row statistics (ABI 2)
+    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 32   # split-K arrival counters (ABI 2)
+    assert VdGemmDesc.ln_stats.offset == ctypes.sizeof(VdGemmDesc) - 24   # LayerNorm-fold row statistics (ABI 2)
+    assert VdGemmDesc.out_stats.offset == ctypes.sizeof(VdGemmDesc) - 16   # producer-emitted GroupNorm statistics (ABI 5)
 
 
 def test_model_cfg_bank_resolves_four_flow():
@@ -314,3 +315,35 @@ def test_registry_weight_sources_and_model_args(tmp_path, monkeypatch):
     assert type(w.backbone).__name__ == "AutoencoderKL" and w.act.negative_slope == 0.2
     assert get_unit()("conv(kernel_size=(3,3), padding=1)")(4, 8).kernel_size == (3, 3)
     assert preprocess_model_args({"a": 1}) == {"a": 1}
+
+
+# ---- round 4 -------------------------------------------------------------------------------------------------------
+
+def test_bench_never_reports_one_gpu_for_a_multi_gpu_request():
+    """`python bench.py --gpus 8` outside torchrun must launch 8 ranks or fail -- never print an n_gpus: 1 line (round-3
+    review).  On this GPU-less host: non-zero exit, no JSON on stdout, for both the bare and the WORLD_SIZE-mismatch form."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
+    assert "8" in r.stderr and "GPU" in r.stderr
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=2" in r.stderr
+
+
+def test_draw_initial_latent_device_generator_is_the_reference_draw():
+    """device_generator=True: torch.manual_seed(seed + 100) then torch.randn(shape, device, dtype) -- the draw of the
+    reference's unsharded call (app.py:309 -> ddim.py:105); the default host-generator draw differs and is seed-stable."""
+    import torch
+    from lib.model_zoo import sharded
+    shape = (3, 4, 8, 8)
+    a = sharded.draw_initial_latent(shape, 7, dtype=torch.float32, device_generator=True, device="cpu")
+    torch.manual_seed(107)
+    assert torch.equal(a, torch.randn(shape))
+    b = sharded.draw_initial_latent(shape, 7)
+    assert torch.equal(b, sharded.draw_initial_latent(shape, 7)) and b.shape == a.shape

@@ -866,3 +866,136 @@ def test_adjust_rank_batched_and_257_tokens(ops, dev):
     for lvl in (0.2, 0.9):
         y = ar(x.to(dev), lvl)
         assert rel_l2(y.cpu(), A.exact(x.float(), lvl)) < 2e-3, lvl
+
+
+# ---- round 4: GroupNorm from producer-emitted per-channel statistics (csrc/gn_fused.hip) ---------------------------------
+
+def _chan_stats_ref(x, B, T):
+    """(mean, M2) per channel over T blocks of HW / T rows per sample, torch fp32/fp64 on the fp16 values."""
+    C = x.shape[-1]
+    xb = x.double().reshape(B * T, -1, C)
+    mean = xb.mean(1)
+    m2 = ((xb - mean[:, None, :]) ** 2).sum(1)
+    return torch.stack([mean, m2], -1).float()
+
+
+def _stats_close(st, ref, rows):
+    """mean to fp32 accuracy, M2 to 1e-3 of its scale (sum over `rows` values of O(1) deviations)."""
+    assert st.buf.shape == ref.shape
+    dm = (st.buf[..., 0] - ref[..., 0]).abs().max().item()
+    scale = ref[..., 1].abs().max().item() + 1e-6
+    d2 = (st.buf[..., 1] - ref[..., 1]).abs().max().item() / scale
+    assert dm < 2e-4 and d2 < 1e-3, (dm, d2)
+
+
+@pytest.mark.parametrize("B,HW,C,R", [(2, 4096, 320, 256), (3, 1024, 640, 64), (2, 256, 1280, 256), (4, 64, 1280, 64),
+                                      (1, 4096, 200, 128), (2, 300, 64, 100)])
+def test_chan_stats(ops, dev, B, HW, C, R):
+    x = rnd((B, HW, C), dev, 2.0, 200) + 0.7
+    st = ops.chan_stats(x, R)
+    assert st.T == HW // R and st.C == C and st.HW == HW
+    _stats_close(st, _chan_stats_ref(x, B, HW // R), R)
+
+
+@pytest.mark.parametrize("B,HW,c0,c1,R0,R1,silu,eps", [
+    (2, 4096, 320, 0, 256, 0, True, 1e-5), (2, 4096, 640, 320, 128, 256, True, 1e-5), (3, 1024, 640, 640, 64, 256, True, 1e-5),
+    (2, 256, 1280, 1280, 256, 64, True, 1e-5), (4, 64, 1280, 0, 64, 0, False, 1e-6), (2, 4096, 320, 0, 64, 0, False, 1e-6),
+    (1, 1024, 1280, 640, 64, 64, True, 1e-5), (1, 16384, 128, 0, 256, 0, True, 1e-6), (2, 1024, 512, 0, 256, 0, True, 1e-6)])
+def test_groupnorm_from_stats(ops, dev, B, HW, c0, c1, R0, R1, silu, eps):
+    """vd_groupnorm_from_stats_f16 (partials of either source in its own block size) against torch's GroupNorm; also the
+    table form (vd_gn_table_f32 + vd_gn_apply_table_f16) and the dispatch inside ops.groupnorm_silu."""
+    x0 = rnd((B, HW, c0), dev, 2.0, 210) + 0.5
+    x1 = rnd((B, HW, c1), dev, 1.0, 211) - 0.3 if c1 else None
+    C = c0 + c1
+    gamma = rnd((C,), dev, 0.5, 212) + 1.0
+    beta = rnd((C,), dev, 0.5, 213)
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    st0 = ops.chan_stats(x0, R0)
+    st1 = ops.chan_stats(x1, R1) if c1 else None
+    out = ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu)
+    assert out.shape == (B, HW, C) and rel_l2(out, ref) < 2e-3
+    table = ops.gn_table(st0, gamma, beta, st1=st1, B=B, groups=32, eps=eps)
+    out2 = ops.gn_apply_table(x0, table, x1=x1, silu=silu)
+    assert rel_l2(out2, ref) < 2e-3
+    # dispatch: statistics riding on the tensors (one source measured on the fly when only the other carries them)
+    x0._vd_stats = st0
+    out3 = ops.groupnorm_silu(x0, gamma, beta, x1=x1, groups=32, eps=eps, silu=silu)
+    assert rel_l2(out3, ref) < 2e-3
+    if ops.GN_STATS:
+        assert torch.equal(out3, ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=ops.chan_stats(x1) if c1 else None,
+                                                          groups=32, eps=eps, silu=silu)) or c1   # same kernel, same partials
+    # run-to-run identical (no atomics)
+    assert torch.equal(out, ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu))
+
+
+@pytest.mark.parametrize("HW,C,R", [(4096, 320, 256), (256, 1280, 64), (64, 1280, 64)])
+def test_gn_fused_large_mean_small_spread(ops, dev, HW, C, R):
+    """|mean| >> sigma with eps = 1e-6: shifted partial sums + Chan's combination must match torch's two-pass statistics
+    (the producers' epilogues use the same shifted form, checked against chan_stats in test_gemm_out_stats)."""
+    g = torch.Generator().manual_seed(170 + HW)
+    x = (16.0 + 0.03 * torch.randn((2, HW, C), generator=g)).half().to(dev)
+    gamma = rnd((C,), dev, 0.5, 171) + 1.0
+    beta = rnd((C,), dev, 0.5, 172)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-6).permute(0, 2, 1)
+    out = ops.groupnorm_from_stats(x, gamma, beta, ops.chan_stats(x, R), groups=32, eps=1e-6, silu=False)
+    assert rel_l2(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, c0, c1, Co, ksize, stride, ups, rowvec, residual
+    (8, 64, 64, 320, 0, 320, 3, 1, 0, True, False),     # halo conv, one block per patch, epilogue statistics
+    (8, 64, 64, 64, 64, 320, 3, 1, 0, False, True),
+    (8, 32, 32, 128, 0, 640, 3, 1, 0, False, False),    # ... 4 column tiles, no split
+    (2, 64, 64, 320, 0, 320, 3, 1, 0, True, False),     # few patches: split over chunks, statistics from the reduce kernel
+    (2, 32, 32, 640, 640, 640, 3, 1, 0, True, False),   # halo conv split over chunks: statistics from the reduce kernel
+    (4, 16, 16, 1280, 0, 1280, 3, 1, 0, False, True),
+    (8, 8, 8, 1280, 0, 1280, 3, 1, 0, True, False),     # 8x8 level: gemm_f16_kernel + deep split-K + reduce
+    (2, 16, 16, 640, 0, 640, 3, 1, 1, False, False),    # Upsample conv
+    (2, 64, 64, 320, 0, 320, 3, 2, 0, False, False),    # Downsample (stride 2) on gemm_f16_kernel
+    (2, 64, 64, 320, 0, 320, 1, 1, 0, False, True),     # SpatialTransformer.proj_out (1x1 + residual)
+    (2, 16, 16, 1280, 0, 1280, 1, 1, 0, False, True),
+    (8, 8, 8, 1280, 0, 1280, 1, 1, 0, False, True),     # tiles span several 8x8 images: one partial per image
+    (1, 96, 96, 320, 0, 320, 3, 1, 0, True, False),     # 768x768 geometry
+])
+def test_gemm_out_stats(ops, dev, case):
+    """VdGemmDesc.out_stats of every producer of the UNet's data flow: the partials attached to the output describe the
+    STORED fp16 tensor (chan_stats of it, same block size), and the output itself is unchanged by the request."""
+    from vd_hip.pack import pack_conv_weight
+    B, H, W, c0, c1, Co, ks, stride, ups, rv, rs = case
+    x = rnd((B, H, W, c0), dev, 1.0, 300)
+    x1 = rnd((B, H, W, c1), dev, 1.0, 301) if c1 else None
+    wt = rnd((Co, c0 + c1, ks, ks), dev, 0.04, 302)
+    b = rnd((Co,), dev, 0.3, 303)
+    Ho, Wo = (H << ups) // stride, (W << ups) // stride
+    kw = dict(ksize=ks, stride=stride, pad=ks // 2, ups=ups, x1=x1)
+    if rv:
+        kw.update(rowvec=rnd((B, Co), dev, 0.5, 304), rows_per_batch=Ho * Wo)
+    if rs:
+        kw.update(res=rnd((B, Ho, Wo, Co), dev, 1.0, 305))
+    wp = pack_conv_weight(wt) if ks == 3 else wt.view(Co, c0 + c1).contiguous()
+    plain = ops.conv2d_nhwc(x, wp, b, **kw)
+    out = ops.conv2d_nhwc(x, wp, b, want_stats=True, **kw)
+    assert torch.equal(out, plain) or rel_l2(out, plain) < 1e-6   # (the reduce kernels sum the slabs in the same order)
+    st = ops.stats_of(out)
+    assert st is not None, "this producer should emit statistics"
+    assert st.HW == Ho * Wo and st.C == Co and st.buf.shape == (B * st.T, Co, 2)
+    R = Ho * Wo // st.T
+    if ks == 3 and stride == 1 and Ho * Wo >= 256 and st.T == Ho * Wo // 256:
+        # halo epilogue: a partial is a 256-pixel PATCH of an image (8 x 32 or 16 x 16 pixels), not 256 consecutive rows
+        tw = 32 if Wo % 32 == 0 else 16
+        th = 256 // tw
+        o = out.view(B, Ho // th, th, Wo // tw, tw, Co).permute(0, 1, 3, 2, 4, 5).reshape(B * st.T, 256, Co)
+        ref = torch.stack([o.double().mean(1), ((o.double() - o.double().mean(1, keepdim=True)) ** 2).sum(1)], -1).float()
+    else:
+        ref = _chan_stats_ref(out.view(B, Ho * Wo, Co), B, st.T)
+    _stats_close(st, ref, R)
+    # and a GroupNorm fed with them equals one that measures the tensor itself
+    gamma = rnd((Co,), dev, 0.5, 306) + 1.0
+    beta = rnd((Co,), dev, 0.5, 307)
+    o3 = out.view(B, Ho * Wo, Co)
+    refn = F.silu(F.group_norm(o3.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
+    got = ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True)
+    assert rel_l2(got, refn) < 2e-3

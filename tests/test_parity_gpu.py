@@ -726,3 +726,114 @@ def test_sampler_rng_consumption_matches_reference(tiny, dev, eta):
         torch.randn_like(x)                                       # ddim.py:167
     expect = torch.randn(8, device=dev)
     assert torch.equal(after, expect)
+
+
+# ---- round 4: parity debts named by the round-3 review --------------------------------------------------------------
+
+def test_noise_dropout_with_injected_mask_vs_oracle(tiny, dev, monkeypatch):
+    """noise_dropout > 0 (reference ddim.py:167-169): F.dropout on the step noise.  The noise draws and the dropout masks
+    are injected (torch.randn_like / torch.nn.functional.dropout patched), and the oracle's p_sample_ddim gets the very
+    noise * mask / (1 - p) tensors the reference would add -- values, eta = 0.7, guided."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import synth, vd_oracle as O
+    m = meta()
+    gold = load_gold("ddim_tiny.npz")
+    sd = synth.synth_state_dict(synth.shapes_of(tiny), m["seed"])
+    sd.update(O.register_schedule())
+    steps, eta, scale, p = 5, 0.7, 3.0, 0.3
+    g = torch.Generator().manual_seed(35)
+    noises = [torch.randn((2, 4, 16, 16), generator=g) for _ in range(steps)]
+    masks = [(torch.rand((2, 4, 16, 16), generator=g) >= p).float() / (1.0 - p) for _ in range(steps)]
+    xT, c, u = torch.from_numpy(gold["xT"]), torch.from_numpy(gold["c_text"]), torch.from_numpy(gold["u_text"])
+    plan = O.unet_plan(**m["unet2d"])
+    sched = O.ddim_schedule(sd["alphas_cumprod"], steps, eta)
+    x = xT
+    with torch.no_grad():
+        for i, step in enumerate(np.flip(sched["timesteps"])):
+            index = steps - i - 1
+            x, _ = O.p_sample_ddim(sd, plan, sched, x, [{"type": "text", "conditioning": c, "unconditional_conditioning": u}],
+                                   index, step, scale, global_ptr="image", noise=(noises[i] * masks[i]).half().float())
+    it, im = iter(noises), iter(masks)
+    calls = {"dropout": 0}
+
+    def fake_dropout(t, p=0.5, training=True, inplace=False):
+        calls["dropout"] += 1
+        assert abs(p - 0.3) < 1e-12 and training
+        return (t.float() * next(im).to(t.device)).to(t.dtype)
+
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: next(it).to(device=t.device, dtype=t.dtype))
+    monkeypatch.setattr(torch.nn.functional, "dropout", fake_dropout)
+    z, _ = DDIMSampler(tiny).sample(steps=steps, shape=[2, 4, 16, 16], x_info={"type": "image", "xt": T(gold["xT"], dev)},
+                                    c_info={"type": "text", "conditioning": T(gold["c_text"], dev),
+                                            "unconditional_conditioning": T(gold["u_text"], dev),
+                                            "unconditional_guidance_scale": scale}, eta=eta, noise_dropout=p, verbose=False)
+    assert calls["dropout"] == steps
+    assert rel_l2(z, x) < LATENT_TOL
+
+
+def test_noise_dropout_rng_order_matches_reference(tiny, dev):
+    """Generator consumption with noise_dropout > 0 at eta = 0: per step one randn_like and one dropout mask draw, in
+    that order, after the x_T draw (reference ddim.py:105,167-169); the latents equal the plain eta = 0 run (sigma = 0)."""
+    from lib.model_zoo.ddim import DDIMSampler
+    gold = load_gold("ddim_tiny.npz")
+    steps, shape = 4, [2, 4, 16, 16]
+    ct = {"type": "text", "conditioning": T(gold["c_text"], dev), "unconditional_conditioning": T(gold["u_text"], dev),
+          "unconditional_guidance_scale": 7.5}
+    torch.manual_seed(78)
+    sampler = DDIMSampler(tiny)
+    z, _ = sampler.sample(steps=steps, shape=shape, x_info={"type": "image"}, c_info=dict(ct), eta=0., noise_dropout=0.25,
+                          verbose=False)
+    after = torch.randn(8, device=dev)
+    torch.manual_seed(78)
+    x = torch.randn(shape, device=dev, dtype=torch.float16)
+    for _ in range(len(sampler.ddim_timesteps)):
+        torch.nn.functional.dropout(torch.randn_like(x), p=0.25)
+    assert torch.equal(after, torch.randn(8, device=dev))
+    torch.manual_seed(78)
+    z0, _ = DDIMSampler(tiny).sample(steps=steps, shape=shape, x_info={"type": "image"}, c_info=dict(ct), eta=0., verbose=False)
+    assert rel_l2(z, z0) < 2e-3   # eager loop vs graph-replayed loop of the same kernels
+
+
+def test_sharded_device_generator_reproduces_unsharded_sampler(tiny, dev):
+    """vd_sample_sharded(device_generator=True) on one rank starts from the x_T the reference's unsharded call draws
+    (torch.manual_seed(seed + 100) -> torch.randn(shape, device, fp16), app.py:309 / ddim.py:105): identical images; the
+    default host-generator draw gives a different (world-size invariant) x_T."""
+    from lib.model_zoo import sharded
+    from lib.model_zoo.ddim import DDIMSampler
+    gold = load_gold("ddim_tiny.npz")
+    ct = {"type": "text", "conditioning": T(gold["c_text"], dev), "unconditional_conditioning": T(gold["u_text"], dev)}
+    seed, steps, shape = 5, 4, [2, 4, 16, 16]
+    img = sharded.vd_sample_sharded(tiny, DDIMSampler(tiny), steps, shape, [dict(ct)], seed, device_generator=True)
+    torch.manual_seed(seed + 100)
+    z, _ = DDIMSampler(tiny).sample(steps=steps, shape=shape, x_info={"type": "image"},
+                                    c_info=dict(ct, unconditional_guidance_scale=7.5), eta=0., verbose=False)
+    ref = tiny.vae_decode(z, which="image")
+    assert torch.equal(img, ref)
+    img_host = sharded.vd_sample_sharded(tiny, DDIMSampler(tiny), steps, shape, [dict(ct)], seed)
+    assert not torch.equal(img_host, ref)
+
+
+def test_c2_shape_guided_10_step_loop_batch2_vs_oracle(full, dev, monkeypatch):
+    """BASELINE configs[1] geometry at a batch > 1: B = 2 (CFG batch 4), 64x64x4 latent, L = 77, 10 guided DDIM steps with
+    the graph-replayed loop, full-width model, vs the fp32 CPU oracle -- the captured step at a full-width 64x64 geometry
+    with more than one sample (per-sample GroupNorm statistics, per-image patches, batch-strided attention)."""
+    from lib.model_zoo.ddim import DDIMSampler
+    from oracle import vd_oracle as O
+    net, sd = full
+    g = torch.Generator().manual_seed(41)
+    xT = torch.randn((2, 4, 64, 64), generator=g)
+    c = torch.randn((2, 77, 768), generator=g) * 0.5
+    u = (torch.randn((1, 77, 768), generator=g) * 0.5).repeat(2, 1, 1)
+    with torch.no_grad():
+        zref, _ = O.ddim_sample(sd, O.unet_plan(), sd["alphas_cumprod"], xT,
+                                [{"type": "text", "conditioning": c, "unconditional_conditioning": u}], 10, 7.5,
+                                global_ptr="image")
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: xT.half().to(dev))
+    z, _ = DDIMSampler(net).sample(steps=10, shape=[2, 4, 64, 64], x_info={"type": "image"},
+                                   c_info={"type": "text", "conditioning": c.half().to(dev),
+                                           "unconditional_conditioning": u.half().to(dev),
+                                           "unconditional_guidance_scale": 7.5}, eta=0., verbose=False)
+    err = rel_l2(z, zref)
+    per_sample = [rel_l2(z[i], zref[i]) for i in range(2)]
+    print("C2-shape 10-step B=2 rel-L2 vs fp32 oracle: %.3e (per sample %s)" % (err, per_sample))
+    assert err < LATENT_TOL and max(per_sample) < LATENT_TOL

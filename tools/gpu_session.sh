@@ -1,0 +1,51 @@
+#!/bin/bash
+# One parametrised gpurun session script (round 4 on; replaces the per-session gpu_r0*_*.sh files).
+#   tools/gpu_session.sh <out-subdir> <step> [<step> ...]
+# steps:
+#   tests:<pytest -k expression>   pytest -m gpu restricted to the expression ("all" = the whole GPU suite)
+#   fwd[:ENV=V,ENV=V]              graph-replayed UNet forward at the bench shape (tools/unet_forward.py 3 graph) under the env
+#   shape[:ENV=V,...]              per-shape table of one instrumented forward (tools/shape_profile.py)
+#   bench[:args]                   python bench.py <args>   (commas separate arguments)
+#   trace                          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.csv / breakdown
+#   pmc                            FETCH_SIZE / WRITE_SIZE passes over the forward -> pmc_traffic.json
+#   py:<script and args>           python tools/<script> (commas separate arguments)
+cd "$(dirname "$0")/.." && export VD_QUIET=1
+R=$PWD; O=$R/gpurun_out/$1; shift; mkdir -p $O
+envrun() {   # envrun "A=1,B=2" cmd...
+    local e="$1"; shift
+    if [ -n "$e" ]; then env $(echo "$e" | tr ',' ' ') "$@"; else "$@"; fi
+}
+n=0
+for step in "$@"; do
+    n=$((n+1)); kind=${step%%:*}; arg=""; [ "$step" != "$kind" ] && arg=${step#*:}
+    tag=$(printf "%02d_%s" $n "$(echo "$step" | tr -c 'A-Za-z0-9_=.-' '_' | cut -c1-60)")
+    echo "=== [$n] $step"
+    case $kind in
+    tests)
+        if [ "$arg" = "all" ]; then timeout 2400 python -m pytest tests -m gpu -x -q > $O/$tag.log 2>&1
+        else timeout 1800 python -m pytest tests -m gpu -x -q -k "$arg" > $O/$tag.log 2>&1; fi
+        echo "rc=$?"; tail -6 $O/$tag.log ;;
+    fwd)
+        envrun "$arg" timeout 600 python tools/unet_forward.py 3 graph > $O/$tag.log 2>&1; echo "rc=$?"; tail -3 $O/$tag.log ;;
+    shape)
+        envrun "$arg" timeout 600 python tools/shape_profile.py > $O/$tag.txt 2>&1; echo "rc=$?"; head -40 $O/$tag.txt ;;
+    bench)
+        timeout 1500 python bench.py $(echo "$arg" | tr ',' ' ') > $O/$tag.json 2> $O/$tag.err; echo "rc=$?"; tail -1 $O/$tag.json | cut -c1-1500 ;;
+    trace)
+        (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/$tag.log 2>&1); echo "rc=$?"
+        DB=$(find $O/prof_bench -name "*.db" | head -1)
+        python tools/kernel_stats.py $DB > $O/kernel_stats.csv 2> $O/kernel_stats.err; head -12 $O/kernel_stats.csv | cut -c1-220
+        NF=$(python tools/count_forwards.py $DB); echo "forwards in the traced run: $NF"
+        python tools/kernel_breakdown.py $DB $NF > $O/kernel_breakdown.txt 2>&1; head -30 $O/kernel_breakdown.txt
+        rm -rf $O/prof_bench ;;
+    pmc)
+        (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python $R/tools/unet_forward.py 3 > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+         timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python $R/tools/unet_forward.py 3 > $O/pmc_write.log 2>&1; echo "pmc write rc=$?")
+        F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
+        python tools/pmc_traffic.py $F $W > $O/pmc_traffic.json 2> $O/pmc_traffic.err; echo "traffic rc=$? $(wc -c < $O/pmc_traffic.json) bytes"
+        rm -rf $O/pmc_fetch $O/pmc_write ;;
+    py)
+        timeout 900 python tools/$(echo "$arg" | tr ',' ' ') > $O/$tag.log 2>&1; echo "rc=$?"; tail -25 $O/$tag.log ;;
+    *) echo "unknown step $step" ;;
+    esac
+done

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
 OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "ff_fused.hip", "gemm_row320.hip", "norm.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "ff_fused.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "conv_halo_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the
@@ -65,16 +65,24 @@ def build(force=False, verbose=False):
             continue
         if verbose:
             print(" ".join(cmd))
+        # the old stamp goes BEFORE hipcc overwrites the object: an interrupted or failed compile must not leave a stamp that
+        # vouches for a truncated / newer object
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), ostamp, h.hexdigest()))
-    for s, p, ostamp, odg in procs:
+    failed = []
+    for s, p, ostamp, odg in procs:   # reap EVERY compiler process before reporting a failure
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on %s" % s)
+            failed.append(s)
+            continue
         with open(ostamp, "w") as f:
             f.write(odg)
         if verbose and out:
             print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     subprocess.check_call(cmd)
     with open(stamp, "w") as f:

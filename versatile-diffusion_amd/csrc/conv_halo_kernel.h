@@ -514,7 +514,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             unsigned spins = 0;
             while (__hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 24)) break;   // never seen; a bounded wait cannot hang the device
+                // never seen (ticket holders are resident).  A bounded wait cannot hang the device, and giving up must not
+                // look like success: trap -- the launch fails, the host sees the error, the counters are NOT re-armed
+                if (++spins > (1u << 24)) __builtin_trap();
             }
             __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
             __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -571,6 +573,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     const bool want_rv = (e.flags & VD_EPI_ROWVEC) != 0;
     const bool ld_ok = ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
     const bool rv_per_image = e.rows_per_batch == p.Hv * p.Wv;
+    // d.out_stats: per-channel statistics of the stored tile for a consuming GroupNorm (gemm_kernel.h: emit_chan_stats);
+    // part 2 then writes what it stores back into the tile
+    const bool want_stats = d.out_stats != nullptr && p.g.stat_rows > 0;
     auto rv_index = [&](int m, int row) { return rv_per_image ? img0 + (m >> p.lgsz) : row / e.rows_per_batch; };
     // few segments per thread: request them now; many (one wave per SIMD): read in line, the registers are not there
     constexpr bool PREFETCH = MAX_CH <= 12;
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                 f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
                 if (p.g.nt_store) vd_store16_nt(dst, o.u);
                 else *reinterpret_cast<uint4*>(dst) = o.u;
+                if (want_stats) *reinterpret_cast<uint4*>(cs + r * CS_LD + cc) = o.u;
             } else {   // unaligned leading dimensions: element-wise tail of gemm_f16_kernel
                 float v[8];
 #pragma unroll
@@ -651,12 +657,19 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             }
         }
     }
+    // one partial per patch (a patch lies in one image), or per image where a patch holds several whole small images
+    if (want_stats) {
+        __syncthreads();
+        const int nsub = p.ngrp, R = BM / p.ngrp;
+        emit_chan_stats<BN, CS_LD, NT>(cs, reinterpret_cast<float*>(smem + BM * CS_LD * 2), tid, R, nsub, nsub, d.out_stats,
+                                       (size_t)tm * nsub, d.N, n0);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int NT, int MODE>
 int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
     constexpr int WST = MODE == 0 ? 2 : 3;
-    constexpr int EPI = BM * (BN + 8) * 2;
+    constexpr int EPI = stat_lds_bytes(BM, BN);   // epilogue tile + the lane scratch of the statistics pass
     const int main_bytes = 2 * a.halo_bytes + WST * (MODE == 4 ? 9 : 1) * BN * 128;
     const int lds = main_bytes > EPI ? main_bytes : EPI;
     if (lds > 160 * 1024) {

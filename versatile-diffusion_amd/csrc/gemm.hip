@@ -59,6 +59,76 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     }
 }
 
+// The same reduction for outputs that feed a GroupNorm (VdGemmDesc.out_stats): a block owns 64 rows x 64 columns, sums the
+// slabs, runs the fused epilogue and emits per-channel (mean, M2) of the 64 values it stored per channel (csrc/gn_fused.hip).
+// grid (ceil(N / 64), M / 64), 256 threads = 8 column octets x 32 row lanes (2 rows each)
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs p, int nsplit) {
+    __shared__ float red[32][64][2];
+    __shared__ float pivot[64];
+    const VdGemmDesc& d = p.d;
+    const EpiCtx e = make_epi(d, 0);
+    const int tid = threadIdx.x, co = tid & 7, rl = tid >> 3;
+    const int col = blockIdx.x * 64 + co * 8;
+    const int row0 = blockIdx.y * 64;
+    const size_t slab = (size_t)d.M * d.N;
+    float fin[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fin[u][i] = 0.f;
+    if (col < d.N) {   // N % 8 == 0: whole octets
+        float v[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
+        const float* w0 = d.ws + (size_t)(row0 + rl) * d.N + col;
+        for (int s = 0; s < nsplit; ++s) {
+            float4 x[2], y[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float* w = w0 + (size_t)s * slab + (size_t)(32 * u) * d.N;
+                x[u] = *reinterpret_cast<const float4*>(w);
+                y[u] = *reinterpret_cast<const float4*>(w + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                v[u][0] += x[u].x; v[u][1] += x[u].y; v[u][2] += x[u].z; v[u][3] += x[u].w;
+                v[u][4] += y[u].x; v[u][5] += y[u].y; v[u][6] += y[u].z; v[u][7] += y[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            epi_store8(e, row0 + rl + 32 * u, col, v[u]);   // v: the values before the fp16 store
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fin[u][i] = (float)(f16)v[u][i];
+        }
+    }
+    if (rl == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pivot[co * 8 + i] = fin[0][i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float k = pivot[co * 8 + i];
+        const float a0 = fin[0][i] - k, a1 = fin[1][i] - k;
+        red[rl][co * 8 + i][0] = a0 + a1;
+        red[rl][co * 8 + i][1] = a0 * a0 + a1 * a1;
+    }
+    __syncthreads();
+    if (tid < 64 && blockIdx.x * 64 + tid < d.N) {
+        float S = 0.f, Q = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < 32; ++l) {
+            S += red[l][tid][0];
+            Q += red[l][tid][1];
+        }
+        reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * 64 + tid] =
+            make_float2(pivot[tid] + S / 64.f, fmaxf(Q - S * S / 64.f, 0.f));
+    }
+}
+
 }  // namespace
 
 extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
@@ -111,6 +181,40 @@ inline int epi_class(const VdGemmDesc& d) {
     return (d.act == VD_ACT_GEGLU ? 1 : 0) | ((d.flags & VD_EPI_LNFOLD) ? 2 : 0) | (d.a1 ? 4 : 0);
 }
 
+// which gemm_f16_kernel instances (as launched below) can emit VdGemmDesc.out_stats from their epilogue
+bool cfg_emits_stats(int cfg) {
+    switch (cfg) {
+        case T128x128: return gemm_emits_stats<128, 128, 256, 2, 64, false>();
+        case T128x64: return gemm_emits_stats<128, 64, 256, 2, 64, false>();
+        case T64x64: return gemm_emits_stats<64, 64, 256, 2, 64, false>();
+        case T128x128w8: return gemm_emits_stats<128, 128, 512, 2, 64, false>();
+        case T128x64w8: return gemm_emits_stats<128, 64, 512, 2, 64, false>();
+        case T128x320: return gemm_emits_stats<128, 320, 512, 2, 64, false>();
+        case T128x160: return gemm_emits_stats<128, 160, 256, 2, 64, false>();
+        case T128x128d: return gemm_emits_stats<128, 128, 256, 3, 64, false>();
+        case T128x64d: return gemm_emits_stats<128, 64, 256, 3, 64, false>();
+        case T64x64d: return gemm_emits_stats<64, 64, 256, 3, 64, false>();
+        default: return false;   // development tiles: the host falls back to vd_chan_stats_f16
+    }
+}
+
+// rows per statistics partial the planned launch writes to d.out_stats (0: it cannot)
+int plan_stat_rows(const GemmArgs& a, int cfg, int nsplit, const ConvHaloArgs* halo) {
+    const VdGemmDesc& d = a.d;
+    if (d.batch != 1 || (d.flags & (VD_EPI_OUT_F32 | VD_EPI_LNFOLD | VD_EPI_BIAS_ALONG_M)) || d.act == VD_ACT_GEGLU) return 0;
+    if (d.N % 8 != 0 || d.ldc % 8 != 0 || ((d.flags & VD_EPI_RESIDUAL) && d.ldr % 8 != 0)) return 0;
+    const int HW = d.stat_img_rows;
+    if (HW <= 0 || d.M % HW != 0) return 0;
+    if (nsplit > 1) return (d.sync == nullptr && HW % 64 == 0) ? 64 : 0;   // splitk_reduce_stats_kernel
+    if (cfg >= T_COUNT) {
+        if (halo == nullptr || HW != halo->Hv * halo->Wv) return 0;
+        return halo->ngrp == 1 ? d.M / halo->g.tiles_m : HW;
+    }
+    if (!cfg_emits_stats(cfg)) return 0;
+    const int bm = kCfg[cfg].bm;
+    return HW % bm == 0 ? bm : (bm % HW == 0 ? HW : 0);
+}
+
 // validate + normalise the descriptor and pick tile shape / split factor
 int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, ConvHaloArgs* halo = nullptr) {
     VD_REQUIRE(dp != nullptr, "vd_gemm_f16: null descriptor");
@@ -136,6 +240,8 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         d.Hin = 1; d.Win = d.M; d.Hout = 1; d.Wout = d.M; d.pad = 0; d.stride = 1; d.ups = 0;
     }
     VD_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "vd_gemm_f16: M=%d is not a multiple of Hout*Wout=%d", d.M, d.Hout * d.Wout);
+    if (d.stat_img_rows <= 0) d.stat_img_rows = d.Hout * d.Wout;
+    a.stat_rows = 0;
     const int n_out = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
     if (d.ldc <= 0) d.ldc = n_out;
     if (d.ldr <= 0) d.ldr = n_out;
@@ -151,7 +257,12 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         VD_REQUIRE(!(d.flags & (VD_EPI_ROWVEC | VD_EPI_RESIDUAL)) && d.act != VD_ACT_GEGLU, "vd_gemm_f16: fp32 output supports bias/act/alpha only");
     const bool lnfold = (d.flags & VD_EPI_LNFOLD) != 0;
     if (lnfold) {
-        VD_REQUIRE(d.colsum != nullptr, "vd_gemm_f16: LayerNorm fold needs colsum");   // ln_stats NULL: statistics inside the K loop
+        VD_REQUIRE(d.colsum != nullptr, "vd_gemm_f16: LayerNorm fold needs colsum");
+        // statistics inside the K loop (one-pass E[x^2] - mean^2 on the raw fp16 operands, less robust than the two-pass
+        // vd_row_stats_f16) only on explicit request: a forgotten ln_stats pointer is an error, not a silent downgrade
+        VD_REQUIRE(d.ln_stats != nullptr || (d.flags & VD_EPI_LN_INLOOP),
+                   "vd_gemm_f16: LayerNorm fold needs ln_stats (or VD_EPI_LN_INLOOP for in-loop statistics)");
+        VD_REQUIRE(d.ln_stats == nullptr || !(d.flags & VD_EPI_LN_INLOOP), "vd_gemm_f16: VD_EPI_LN_INLOOP takes no ln_stats");
         VD_REQUIRE(d.ksize == 1 && d.a1 == nullptr && d.split_k <= 1 && !(d.flags & (VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M)),
                    "vd_gemm_f16: LayerNorm fold takes a plain single-source A, fp16 output, no split-K");
         VD_REQUIRE(((size_t)d.colsum & 15) == 0 && ((size_t)d.ln_stats & 7) == 0, "vd_gemm_f16: colsum must be 16-byte, ln_stats 8-byte aligned");
@@ -201,7 +312,14 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     };
     // 3x3 convolutions on patch-shaped output grids: the halo-resident kernel (conv_halo.hip), unless a GEMM tile is forced
     static const bool tile_env = getenv("VD_GEMM_TILE") != nullptr;
-    if (d.ksize == 3 && g_override.load(std::memory_order_relaxed) < 0 && !tile_env) {
+    bool tuned_gemm_tile = false;   // a tuned-table entry for this 3x3 problem pins a gemm_f16_kernel tile: it vetoes the halo path
+    if (d.ksize == 3) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        const int cls = epi_class(d);
+        for (const TuneEntry& t : g_tune)
+            if (t.M == d.M && t.N == d.N && t.K == d.K && t.ks == 3 && t.cls == cls && d.batch == 1) { tuned_gemm_tile = true; break; }
+    }
+    if (d.ksize == 3 && g_override.load(std::memory_order_relaxed) < 0 && !tile_env && !tuned_gemm_tile) {
         ConvHaloArgs local;
         ConvHaloArgs* h = halo ? halo : &local;
         int hv = 0, hns = 1;
@@ -215,6 +333,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
             a.kt_per_split = a.kt_total;
             cfg_out = T_COUNT + hv;
             nsplit_out = hns;
+            a.stat_rows = h->g.stat_rows = plan_stat_rows(a, cfg_out, hns, h);
             return VD_OK;
         }
     }
@@ -344,9 +463,22 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     nsplit = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
     cfg_out = (int)cfg;
     nsplit_out = nsplit;
+    a.stat_rows = plan_stat_rows(a, cfg_out, nsplit, nullptr);
     return VD_OK;
 }
 }  // namespace
+
+extern "C" int vd_gemm_stat_rows(const VdGemmDesc* dp, int* rows) {
+    GemmArgs a;
+    ConvHaloArgs halo;
+    int c = 0, n = 1;
+    const int rc = plan_gemm(dp, a, c, n, &halo);
+    if (rc != VD_OK) return rc;
+    // the split-K in-kernel fix-up is decided at launch (vd_gemm_f16 drops d.sync when the tiles outnumber the counters);
+    // plan_stat_rows already answers 0 whenever the caller supplied counters
+    if (rows) *rows = a.stat_rows;
+    return VD_OK;
+}
 
 extern "C" int vd_gemm_plan(const VdGemmDesc* dp, int* tile_cfg, int* nsplit) {
     GemmArgs a;
@@ -392,6 +524,11 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     int rc = plan_gemm(dp, a, cfg, nsplit, &halo);
     if (rc != VD_OK) return rc;
     const VdGemmDesc& d = a.d;
+    if (d.out_stats != nullptr && a.stat_rows == 0) {
+        vd_set_error("vd_gemm_f16: out_stats requested but the planned launch cannot emit statistics (vd_gemm_stat_rows = 0)");
+        return VD_ERR_UNSUPPORTED;
+    }
+    VD_REQUIRE(((size_t)d.out_stats & 7) == 0, "vd_gemm_f16: out_stats must be 8-byte aligned");
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
@@ -416,6 +553,10 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         if (rc != VD_OK) return rc;
         if (nsplit > 1 && halo.g.d.sync == nullptr) {   // no ticket counters: slabs + the reduce kernel
             a.d.sync = nullptr;
+            if (d.out_stats != nullptr) {
+                hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+                return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
+            }
             const size_t total = (size_t)d.M * ((d.N + 7) / 8);
             int blocks = (int)((total + 255) / 256);
             if (blocks > 4096) blocks = 4096;
@@ -465,6 +606,10 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     }
     if (rc != VD_OK) return rc;
     if (nsplit > 1 && a.d.sync == nullptr) {
+        if (d.out_stats != nullptr) {   // plan_stat_rows: batch 1, fp16 output, whole 64-row blocks per image
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+            return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
+        }
         const size_t total = (size_t)d.M * ((d.N + 7) / 8);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

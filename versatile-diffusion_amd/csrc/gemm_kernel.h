@@ -49,6 +49,7 @@ struct GemmArgs {
     int plain;                             // 1x1, stride 1, no pad / upsample, output grid == input grid
     int nt_store;                          // non-temporal output stores (streaming results that nobody re-reads soon)
     int mfast;                             // XCD tile runs walk m fastest (tiles of one weight column panel share an L2)
+    int stat_rows;                         // d.out_stats: rows per statistics partial (0 = none emitted by this launch)
 };
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
@@ -165,6 +166,63 @@ __device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, fl
     epi_finish8(e, row, col, v);
 }
 
+// ---- per-channel statistics of the stored tile for a consuming GroupNorm (VdGemmDesc.out_stats, csrc/gn_fused.hip) ----
+// The fp16 tile cs[rows][CS_LD] holds the FINAL values (part 2 of the epilogue writes what it stores back into the tile).
+// For each of `nsub` blocks of R consecutive tile rows and each of the BN columns: (mean, M2 = sum (x - mean)^2) over the R
+// rows, accumulated as shifted sums around the block's first row (no cancellation for |mean| >> sigma), written to
+// out[(pbase + s) * N + n0 + c] for s < pvalid.  The first 256 threads work: BN / 8 column octets x STAT_LANES row lanes, the
+// lanes meet in `red` (fp32 [STAT_LANES][BN][2], behind the tile).
+constexpr int stat_lanes(int bn) { return 256 / (bn / 8) < 32 ? 256 / (bn / 8) : 32; }
+constexpr int stat_lds_bytes(int bm, int bn) { return bm * (bn + 8) * 2 + stat_lanes(bn) * bn * 8; }
+
+template <int BN, int CS_LD, int NT>
+__device__ __forceinline__ void emit_chan_stats(const f16* cs, float* red, int tid, int R, int nsub, int pvalid, float* out,
+                                                size_t pbase, int N, int n0) {
+    constexpr int OCT = BN / 8;
+    constexpr int LANES = stat_lanes(BN);
+    const int co = tid % OCT, rl = tid / OCT;
+    for (int s = 0; s < nsub; ++s) {
+        if (s > 0) __syncthreads();   // `red` is re-used
+        const f16* base = cs + (size_t)s * R * CS_LD;
+        if (rl < LANES) {
+            U4H8 kk;
+            kk.u = *reinterpret_cast<const uint4*>(base + co * 8);
+            float S[8], Q[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) S[q] = Q[q] = 0.f;
+            for (int r = rl; r < R; r += LANES) {
+                U4H8 t;
+                t.u = *reinterpret_cast<const uint4*>(base + r * CS_LD + co * 8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = (float)t.e[q] - (float)kk.e[q];
+                    S[q] += v;
+                    Q[q] = fmaf(v, v, Q[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float2*>(red + (rl * BN + co * 8 + q) * 2) = make_float2(S[q], Q[q]);
+        }
+        __syncthreads();
+        if (s < pvalid) {
+            for (int c = tid; c < BN; c += NT) {
+                if (n0 + c < N) {
+                    float S = 0.f, Q = 0.f;
+#pragma unroll 4
+                    for (int l = 0; l < LANES; ++l) {
+                        const float2 v = *reinterpret_cast<const float2*>(red + (l * BN + c) * 2);
+                        S += v.x;
+                        Q += v.y;
+                    }
+                    const float n = (float)R;
+                    *reinterpret_cast<float2*>(out + ((pbase + s) * (size_t)N + n0 + c) * 2) =
+                        make_float2((float)base[c] + S / n, fmaxf(Q - S * S / n, 0.f));
+                }
+            }
+        }
+    }
+}
+
 // Epilogue part 2: the block's fp16 tile (LDS, [BM][CS_LD]) leaves as 16-byte row segments; CH = segments per row.
 // The residual OR the per-batch row vector of a segment (the usual case: a layer has one of them) is requested for ALL
 // of a thread's segments before the accumulators are staged (epi_prefetch), so that latency overlaps part 1; a layer
@@ -191,9 +249,10 @@ __device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int
     }
 }
 
+// keep: the stored values are also written back into the tile (the statistics pass behind part 2 reads them there)
 template <int ROWS, int CH, int NT, int MAX_CH, int CS_LD, int SEG, int WM>
-__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, const f16* cs, const uint4* pre,
-                                             bool nt) {
+__device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, f16* cs, const uint4* pre,
+                                             bool nt, bool keep = false) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
     const bool both = (e.flags & VD_EPI_RESIDUAL) && (e.flags & VD_EPI_ROWVEC);
 #pragma unroll
@@ -217,6 +276,7 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                     f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
                     if (nt) vd_store16_nt(dst, o.u);
                     else *reinterpret_cast<uint4*>(dst) = o.u;
+                    if (keep) *reinterpret_cast<uint4*>(cs + r * CS_LD + cc) = o.u;
                 } else {
                     float v[8];
 #pragma unroll
@@ -236,6 +296,10 @@ __device__ __forceinline__ void wait_vm() {
 
 template <int BM, int BN, int NT, int STAGES, int KB>
 constexpr int gemm_lds_bytes();   // stages / epilogue tile (defined with the launcher below)
+// instances whose epilogue can emit per-channel statistics (VdGemmDesc.out_stats): one epilogue pass, the tile + the lane
+// scratch fit the LDS the main loop owns anyway (occupancy unchanged), not a LayerNorm-fold variant
+template <int BM, int BN, int NT, int STAGES, int KB, bool LNF>
+constexpr bool gemm_emits_stats();
 
 // MID (3 stages, 64-deep tiles only): the main loop of conv3x3_halo_kernel's MODE 2 -- the barrier of a K tile sits BEHIND
 // its first two k-steps, tiles are requested two ahead, operand fragments one k-step ahead in two named register sets with
@@ -797,6 +861,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     // tile [BM][OUT_N]
     f16* cs = reinterpret_cast<f16*>(smem);
     const bool geglu = (d.act == VD_ACT_GEGLU);
+    const bool want_stats = gemm_emits_stats<BM, BN, NT, STAGES, KB, LNF>() && d.out_stats != nullptr && p.stat_rows > 0;
     const int out_n0 = geglu ? tn * (BN / 2) : n0;
 
     const float* ln_cs = reinterpret_cast<const float*>(smem + gemm_lds_bytes<BM, BN, NT, STAGES, KB>());   // block-local colsum
@@ -913,8 +978,20 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 
     // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
     if (geglu) epi_writeout<PROWS, BN / 16, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0);
-    else epi_writeout<PROWS, BN / 8, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0);
+    else epi_writeout<PROWS, BN / 8, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0, want_stats);
     }  // epilogue pass
+
+    // ---- per-channel statistics of the stored tile for a consuming GroupNorm (plan_gemm admits the request only for plain
+    // fp16 epilogues, vector-aligned outputs and tiles whose rows split into whole blocks of p.stat_rows rows of one image)
+    if constexpr (gemm_emits_stats<BM, BN, NT, STAGES, KB, LNF>()) {
+        if (want_stats) {
+            __syncthreads();
+            const int R = p.stat_rows, nsub = BM / R;
+            const int left = (d.M - m0) / R;   // partials of this tile that lie inside the matrix
+            emit_chan_stats<BN, CS_LD, NT>(cs, reinterpret_cast<float*>(smem + BM * CS_LD * 2), tid, R, nsub, left < nsub ? left : nsub,
+                                           d.out_stats, (size_t)(m0 / R), d.N, n0);
+        }
+    }
 }
 
 template <int BM, int BN, int NT, int STAGES, int KB>
@@ -926,8 +1003,17 @@ constexpr int gemm_lds_bytes() {
     return stage > epi ? stage : epi;
 }
 
+template <int BM, int BN, int NT, int STAGES, int KB, bool LNF>
+constexpr bool gemm_emits_stats() {
+    return !LNF && NT >= 256 && (BM * (BN + 8) * 2 + BM * 8 <= 160 * 1024) && stat_lds_bytes(BM, BN) <= gemm_lds_bytes<BM, BN, NT, STAGES, KB>();
+}
+
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false, bool MID = false>
 int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
+    if (a.d.out_stats != nullptr && nsplit == 1 && !gemm_emits_stats<BM, BN, NT, STAGES, KB, LNF>()) {
+        vd_set_error("vd_gemm_f16: this tile configuration cannot emit out_stats (ask vd_gemm_stat_rows first)");
+        return VD_ERR_UNSUPPORTED;
+    }
     constexpr int LDS = gemm_lds_bytes<BM, BN, NT, STAGES, KB>() + (LNF ? BN * 4 : 0);   // + the block's colsum entries
     static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
     // the dynamic-LDS attribute is per device: one bit per device ordinal, set idempotently (safe under concurrent callers)

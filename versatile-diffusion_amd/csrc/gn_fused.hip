@@ -1,0 +1,375 @@
+// GroupNorm without its own passes over memory (round 4).
+//
+// The reference runs GroupNorm32 -> SiLU -> conv as three ops per ResBlock half (lib/model_zoo/openaimodel.py:196-200,
+// 230-237,254-274; normalization(): diffusion_utils.py:175-191; Normalize in front of SpatialTransformer.proj_in:
+// attention.py:76-77,255-259).  Rounds 1-3 ran it as one HBM-bound kernel pair per norm (statistics pass + apply pass,
+// csrc/norm.hip).  Here the norm is split along its data dependences instead:
+//   1. STATISTICS come from whoever PRODUCES the tensor: the epilogues of conv3x3_halo_kernel / gemm_f16_kernel and the
+//      split-K reduce emit, per output channel and per block of `R` rows of one image, the pair (mean, M2 = sum (x - mean)^2)
+//      of the values they store (VdGemmDesc.out_stats).  Per CHANNEL, so a consumer can fold the channels of one tensor --
+//      or of the two tensors of a skip concat -- into its 32 groups whatever the producers' tile shapes were; a tensor that
+//      is consumed twice (every skip connection) is measured once.  vd_chan_stats_f16 computes the same partials with one
+//      read of x for tensors whose producer does not (test reference and fallback).
+//   2. vd_gn_table_f32 folds the partials of one (sample, group) with Chan's parallel-variance update and writes the
+//      normalisation as a per-(sample, channel) affine map  y = x * scale + shift,  scale = rstd * gamma,
+//      shift = beta - mean * rstd * gamma  (fp32 [B][2][C]): a few KB, one tiny launch.
+//   3. The map (+ SiLU) is applied by the CONSUMER: conv3x3_halo_kernel transforms the input halo in LDS once per
+//      64-channel chunk (VdGemmDesc.in_norm, conv_halo_kernel.h), so the normalised activation never exists in HBM;
+//      vd_gn_apply_table_f16 is the one-read one-write elementwise form for consumers without that path.
+// Numerics: partial sums run over (x - k) with k = the block's first row of that channel (a sample, hence within a few
+// sigma of the mean), so M2 = S2 - S1^2 / n does not cancel when |mean| >> sigma; partials are combined as
+// M2 = sum M2_i + sum n_i (mean_i - mean)^2 in fp32 (torch's Welford / two-pass robustness, see
+// tests/test_kernels_gpu.py::test_gn_fused_large_mean_small_spread).
+#include "vd_common.h"
+#include "../../include/vd_hip.h"
+
+namespace {
+
+// ---- 1. per-channel partial statistics of x [M][C] (row stride ldx): one partial per R consecutive rows ---------------
+// grid (ceil(C / 64), M / R), 256 threads = 8 channel octets x 32 row lanes
+__global__ __launch_bounds__(256) void chan_stats_kernel(const f16* __restrict__ x, int ldx, int C, int R, float2* __restrict__ out) {
+    __shared__ float red[32][64][2];
+    const int tid = threadIdx.x, co = tid & 7, rl = tid >> 3;
+    const int c = blockIdx.x * 64 + co * 8;
+    const size_t row0 = (size_t)blockIdx.y * R;
+    float s[8], q[8], k[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = k[i] = 0.f;
+    if (c < C) {
+        U4H8 p;
+        p.u = *reinterpret_cast<const uint4*>(x + row0 * ldx + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = (float)p.e[i];
+        for (int r = rl; r < R; r += 128) {   // 4 loads in flight
+            U4H8 t[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + 32 * u;
+                w[u] = ru < R ? 1.f : 0.f;
+                t[u].u = *reinterpret_cast<const uint4*>(x + (row0 + (ru < R ? ru : r)) * ldx + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = ((float)t[u].e[i] - k[i]) * w[u];
+                    s[i] += v;
+                    q[i] += v * v;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[rl][co * 8 + i][0] = s[i];
+        red[rl][co * 8 + i][1] = q[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int ch = blockIdx.x * 64 + tid;
+        if (ch < C) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll 8
+            for (int l = 0; l < 32; ++l) {
+                S += red[l][tid][0];
+                Q += red[l][tid][1];
+            }
+            const float kk = (float)x[row0 * ldx + ch];
+            const float n = (float)R;
+            out[(size_t)blockIdx.y * C + ch] = make_float2(kk + S / n, fmaxf(Q - S * S / n, 0.f));
+        }
+    }
+}
+
+// ---- 2. partials -> per-(sample, channel) affine map --------------------------------------------------------------------
+struct GnTableArgs {
+    const float2* st0; int T0, c0;   // source 0: [B * T0][c0] partials of HW / T0 rows each
+    const float2* st1; int T1, c1;   // optional source 1 (channel concat)
+    const f16* gamma; const f16* beta;
+    int HW, groups;
+    float eps;
+    float* table;                    // [B][2][c0 + c1]
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// grid (groups, B), 256 threads
+__global__ __launch_bounds__(256) void gn_table_kernel(const GnTableArgs a) {
+    __shared__ float sh[4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int C = a.c0 + a.c1, cg = C / a.groups;
+    const int Tmax = a.T0 > a.T1 ? a.T0 : a.T1;
+    const float n0 = (float)(a.HW / a.T0), n1 = a.T1 > 0 ? (float)(a.HW / a.T1) : 0.f;
+    auto partial = [&](int idx, float& n, float2& p) {   // idx over cg x Tmax; false where the source has fewer partials
+        const int ch = g * cg + idx / Tmax, t = idx % Tmax;
+        if (ch < a.c0) {
+            if (t >= a.T0) return false;
+            n = n0;
+            p = a.st0[((size_t)b * a.T0 + t) * a.c0 + ch];
+        } else {
+            if (t >= a.T1) return false;
+            n = n1;
+            p = a.st1[((size_t)b * a.T1 + t) * a.c1 + (ch - a.c0)];
+        }
+        return true;
+    };
+    float acc = 0.f;
+    for (int idx = tid; idx < cg * Tmax; idx += 256) {
+        float n;
+        float2 p;
+        if (partial(idx, n, p)) acc += n * p.x;
+    }
+    const float ntot = (float)a.HW * (float)cg;
+    const float mean = block_sum_256(acc, sh) / ntot;
+    acc = 0.f;
+    for (int idx = tid; idx < cg * Tmax; idx += 256) {
+        float n;
+        float2 p;
+        if (partial(idx, n, p)) {
+            const float dm = p.x - mean;
+            acc += p.y + n * dm * dm;
+        }
+    }
+    const float var = block_sum_256(acc, sh) / ntot;
+    const float rstd = rsqrtf(var + a.eps);
+    for (int i = tid; i < cg; i += 256) {
+        const int ch = g * cg + i;
+        const float sc = rstd * (float)a.gamma[ch];
+        a.table[((size_t)b * 2) * C + ch] = sc;
+        a.table[((size_t)b * 2 + 1) * C + ch] = (float)a.beta[ch] - mean * sc;
+    }
+}
+
+// ---- 3. elementwise consumer: out[b][p][c] = act(x[b][p][c] * scale[b][c] + shift[b][c]), x = cat(x0, x1) on channels ----
+__global__ __launch_bounds__(256) void gn_apply_table_kernel(const f16* __restrict__ x0, int c0, const f16* __restrict__ x1, int c1,
+                                                             const float* __restrict__ table, int HW, size_t total8, int silu,
+                                                             f16* __restrict__ out) {
+    const int C = c0 + c1, C8 = C / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / C8;
+        const int ch = (int)(i - row * C8) * 8;
+        const int b = (int)(row / HW);
+        const f16* src = ch < c0 ? x0 + row * c0 + ch : x1 + row * c1 + (ch - c0);
+        U4H8 v, o;
+        v.u = *reinterpret_cast<const uint4*>(src);
+        const float4 s0 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2) * C + ch);
+        const float4 s1 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2) * C + ch + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2 + 1) * C + ch);
+        const float4 h1 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2 + 1) * C + ch + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float y = fmaf((float)v.e[q], sc[q], sf[q]);
+            o.e[q] = (f16)(silu ? vd_silu(y) : y);
+        }
+        *reinterpret_cast<uint4*>(out + row * C + ch) = o.u;
+    }
+}
+
+// ---- 2 + 3 in one launch: partials -> (mean, rstd) of the block's groups -> normalise (+SiLU) a [rows x slab] panel ------
+// A block owns one sample, a SLAB of S = lcm(channels per group, 8) channels (whole groups, whole 16-byte octets) and a range
+// of rows; it first folds the partials of its S / cg groups (T x S pairs, L2-resident), then streams its panel once.
+struct GnFromStatsArgs {
+    const f16* x0; const float2* st0; int T0, c0;
+    const f16* x1; const float2* st1; int T1, c1;
+    const f16* gamma; const f16* beta; f16* out;
+    int HW, groups, S, rows_per_block, silu;
+    float eps;
+};
+
+constexpr int GFS_MAXG = 8;   // groups per slab (S / cg): 4 at cg = 10, 2 at cg = 20 / 60, 1 at cg = 40 / 80, 4 at cg = 30
+
+// sum of v[0 .. GFS_MAXG) over the 256 threads of the block, in a fixed order (no atomics: run-to-run identical)
+__device__ __forceinline__ void block_sum_groups(float* v, float (*sh)[GFS_MAXG], float* out, int ng) {
+#pragma unroll
+    for (int g = 0; g < GFS_MAXG; ++g)
+        if (g < ng) v[g] = wave_sum(v[g]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int g = 0; g < GFS_MAXG; ++g) sh[threadIdx.x >> 6][g] = v[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GFS_MAXG; ++g) out[g] = sh[0][g] + sh[1][g] + sh[2][g] + sh[3][g];
+}
+
+// grid (row ranges, slabs, B), 256 threads = S / 8 channel octets x row lanes
+__global__ __launch_bounds__(256) void gn_from_stats_kernel(const GnFromStatsArgs a) {
+    __shared__ float sh[4][GFS_MAXG];
+    const int tid = threadIdx.x, b = blockIdx.z, slab = blockIdx.y;
+    const int C = a.c0 + a.c1, cg = C / a.groups, ng = a.S / cg;
+    const int ch0 = slab * a.S;
+    const int Tmax = a.T0 > a.T1 ? a.T0 : a.T1;
+    const float n0 = (float)(a.HW / a.T0), n1 = a.T1 > 0 ? (float)(a.HW / a.T1) : 0.f;
+    auto partial = [&](int idx, int& gl, float& n, float2& p) {
+        const int cl = idx / Tmax, t = idx - cl * Tmax;
+        const int ch = ch0 + cl;
+        gl = cl / cg;
+        if (ch < a.c0) {
+            if (t >= a.T0) return false;
+            n = n0;
+            p = a.st0[((size_t)b * a.T0 + t) * a.c0 + ch];
+        } else {
+            if (t >= a.T1) return false;
+            n = n1;
+            p = a.st1[((size_t)b * a.T1 + t) * a.c1 + (ch - a.c0)];
+        }
+        return true;
+    };
+    auto add_to = [&](float* v, int gl, float x) {   // v[gl] += x with a compile-time register index
+#pragma unroll
+        for (int g = 0; g < GFS_MAXG; ++g)
+            if (g == gl) v[g] += x;
+    };
+    const int items = a.S * Tmax;
+    const float ntot = (float)a.HW * (float)cg;
+    float acc[GFS_MAXG], mean[GFS_MAXG], m2[GFS_MAXG];
+#pragma unroll
+    for (int g = 0; g < GFS_MAXG; ++g) acc[g] = 0.f;
+    for (int idx = tid; idx < items; idx += 256) {
+        int gl; float n; float2 p;
+        if (partial(idx, gl, n, p)) add_to(acc, gl, n * p.x);
+    }
+    block_sum_groups(acc, sh, mean, ng);
+#pragma unroll
+    for (int g = 0; g < GFS_MAXG; ++g) {
+        mean[g] /= ntot;
+        acc[g] = 0.f;
+    }
+    for (int idx = tid; idx < items; idx += 256) {   // second pass over the (L2-resident) partials
+        int gl; float n; float2 p;
+        if (partial(idx, gl, n, p)) {
+            float mg = 0.f;
+#pragma unroll
+            for (int g = 0; g < GFS_MAXG; ++g)
+                if (g == gl) mg = mean[g];
+            const float dm = p.x - mg;
+            add_to(acc, gl, p.y + n * dm * dm);
+        }
+    }
+    block_sum_groups(acc, sh, m2, ng);
+    const int TC = a.S / 8, RL = 256 / TC;
+    const int tc = tid % TC, rl = tid / TC;
+    if (rl >= RL) return;
+    const int ch = ch0 + tc * 8;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int gl = (tc * 8 + q) / cg;
+        float mg = 0.f, vg = 0.f;
+#pragma unroll
+        for (int g = 0; g < GFS_MAXG; ++g)
+            if (g == gl) { mg = mean[g]; vg = m2[g]; }
+        const float rstd = rsqrtf(vg / ntot + a.eps);
+        sc[q] = rstd * (float)a.gamma[ch + q];
+        sf[q] = (float)a.beta[ch + q] - mg * sc[q];
+    }
+    const bool second = ch >= a.c0;
+    const f16* src = second ? a.x1 + (ch - a.c0) : a.x0 + ch;
+    const int ld = second ? a.c1 : a.c0;
+    const int r0 = blockIdx.x * a.rows_per_block;
+    int r1 = r0 + a.rows_per_block;
+    if (r1 > a.HW) r1 = a.HW;
+    const size_t rowb = (size_t)b * a.HW;
+    for (int r = r0 + rl; r < r1; r += 4 * RL) {   // 4 loads in flight
+        U4H8 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ru = r + u * RL;
+            t[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : r)) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ru = r + u * RL;
+            if (ru < r1) {
+                U4H8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float y = fmaf((float)t[u].e[q], sc[q], sf[q]);
+                    o.e[q] = (f16)(a.silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y)) : y);
+                }
+                *reinterpret_cast<uint4*>(a.out + (rowb + ru) * C + ch) = o.u;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vd_groupnorm_from_stats_f16(const void* x0, int c0, const float* stats0, int T0, const void* x1, int c1,
+                                           const float* stats1, int T1, const void* gamma, const void* beta, void* y, int B, int HW,
+                                           int groups, float eps, int apply_silu, hipStream_t stream) {
+    VD_REQUIRE(x0 && stats0 && gamma && beta && y, "vd_groupnorm_from_stats_f16: null pointer");
+    if (!x1) { c1 = 0; T1 = 0; stats1 = nullptr; }
+    VD_REQUIRE(x1 == nullptr || stats1 != nullptr, "vd_groupnorm_from_stats_f16: x1 without stats1");
+    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && groups > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_groupnorm_from_stats_f16: bad sizes");
+    const int C = c0 + c1;
+    VD_REQUIRE(C % groups == 0, "vd_groupnorm_from_stats_f16: C=%d must divide into %d groups", C, groups);
+    VD_REQUIRE(T0 > 0 && HW % T0 == 0 && (c1 == 0 || (T1 > 0 && HW % T1 == 0)), "vd_groupnorm_from_stats_f16: partials must tile the %d rows of a sample (T0=%d T1=%d)", HW, T0, T1);
+    const int cg = C / groups;
+    int S = cg;   // lcm(cg, 8)
+    while (S % 8 != 0) S += cg;
+    VD_REQUIRE(C % S == 0 && S / cg <= GFS_MAXG && S / 8 <= 256, "vd_groupnorm_from_stats_f16: C=%d with %d groups has no slab (S=%d)", C, groups, S);
+    GnFromStatsArgs a;
+    a.x0 = reinterpret_cast<const f16*>(x0); a.st0 = reinterpret_cast<const float2*>(stats0); a.T0 = T0; a.c0 = c0;
+    a.x1 = reinterpret_cast<const f16*>(x1); a.st1 = reinterpret_cast<const float2*>(stats1); a.T1 = T1; a.c1 = c1;
+    a.gamma = reinterpret_cast<const f16*>(gamma); a.beta = reinterpret_cast<const f16*>(beta); a.out = reinterpret_cast<f16*>(y);
+    a.HW = HW; a.groups = groups; a.S = S; a.silu = apply_silu; a.eps = eps;
+    // row ranges: enough blocks to cover the chip a few times, panels of >= 64 rows so the partial fold stays a small share
+    const int slabs = C / S;
+    int ranges = (1536 + B * slabs - 1) / (B * slabs);
+    int rpb = (HW + ranges - 1) / ranges;
+    if (rpb < 64) rpb = 64;
+    if (rpb > HW) rpb = HW;
+    a.rows_per_block = rpb;
+    ranges = (HW + rpb - 1) / rpb;
+    hipLaunchKernelGGL(gn_from_stats_kernel, dim3(ranges, slabs, B), dim3(256), 0, stream, a);
+    return vd_check_launch("vd_groupnorm_from_stats_f16");
+}
+
+extern "C" int vd_chan_stats_f16(const void* x, long M, int C, int ldx, int rows_per_partial, float* stats, hipStream_t stream) {
+    VD_REQUIRE(x && stats, "vd_chan_stats_f16: null pointer");
+    VD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0, "vd_chan_stats_f16: M=%ld C=%d ldx=%d (C, ldx multiples of 8)", M, C, ldx);
+    VD_REQUIRE(rows_per_partial > 0 && M % rows_per_partial == 0, "vd_chan_stats_f16: M=%ld is not a multiple of rows_per_partial=%d", M, rows_per_partial);
+    VD_REQUIRE(M / rows_per_partial <= 65535, "vd_chan_stats_f16: %ld partials > 65535", M / rows_per_partial);
+    hipLaunchKernelGGL(chan_stats_kernel, dim3((C + 63) / 64, (unsigned)(M / rows_per_partial)), dim3(256), 0, stream,
+                       reinterpret_cast<const f16*>(x), ldx, C, rows_per_partial, reinterpret_cast<float2*>(stats));
+    return vd_check_launch("vd_chan_stats_f16");
+}
+
+extern "C" int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
+                               const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream) {
+    VD_REQUIRE(stats0 && gamma && beta && table, "vd_gn_table_f32: null pointer");
+    if (!stats1) { T1 = 0; c1 = 0; }
+    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && groups > 0 && c0 > 0 && c1 >= 0, "vd_gn_table_f32: bad sizes");
+    VD_REQUIRE((c0 + c1) % groups == 0 && (c0 + c1) % 4 == 0, "vd_gn_table_f32: C=%d must divide into %d groups", c0 + c1, groups);
+    VD_REQUIRE(T0 > 0 && HW % T0 == 0 && (c1 == 0 || (T1 > 0 && HW % T1 == 0)), "vd_gn_table_f32: partials must tile the %d rows of a sample (T0=%d T1=%d)", HW, T0, T1);
+    GnTableArgs a;
+    a.st0 = reinterpret_cast<const float2*>(stats0); a.T0 = T0; a.c0 = c0;
+    a.st1 = reinterpret_cast<const float2*>(stats1); a.T1 = T1; a.c1 = c1;
+    a.gamma = reinterpret_cast<const f16*>(gamma); a.beta = reinterpret_cast<const f16*>(beta);
+    a.HW = HW; a.groups = groups; a.eps = eps; a.table = table;
+    hipLaunchKernelGGL(gn_table_kernel, dim3(groups, B), dim3(256), 0, stream, a);
+    return vd_check_launch("vd_gn_table_f32");
+}
+
+extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int silu,
+                                     void* out, hipStream_t stream) {
+    VD_REQUIRE(x0 && table && out, "vd_gn_apply_table_f16: null pointer");
+    if (!x1) c1 = 0;
+    VD_REQUIRE(B > 0 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
+    const size_t total8 = (size_t)B * HW * ((c0 + c1) / 8);
+    size_t blocks = (total8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gn_apply_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const f16*>(x0), c0,
+                       reinterpret_cast<const f16*>(x1), c1, table, HW, total8, silu, reinterpret_cast<f16*>(out));
+    return vd_check_launch("vd_gn_apply_table_f16");
+}

@@ -190,7 +190,7 @@ class SpatialTransformer(nn.Module):
             w2, b2, _ = blk.attn1._w_qkv_ln(blk.norm1)
             h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps)
             h = blk(h, context=context, kv=kv, qkv=qkv)
-            return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res)
+            return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)
         h = self.proj_in(self.norm(x, silu=False))
         h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv)
-        return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res)
+        return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)

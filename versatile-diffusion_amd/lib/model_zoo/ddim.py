@@ -93,7 +93,6 @@ class DDIMSampler(object):
             return self._ddim_sampling_multicontext(shape, x_info, c_info_list, noise_dropout, temperature, log_every_t, _single)
 
     def _ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout, temperature, log_every_t, _single):
-        assert noise_dropout == 0., "noise_dropout is a training-time option"
         device = self.model.device
         dtype = c_info_list[0]["conditioning"].dtype
         bs = shape[0]
@@ -131,14 +130,17 @@ class DDIMSampler(object):
         total_steps = timesteps.shape[0]
         x = x_info["x"].to(torch.float16).contiguous()
         eta_zero = bool(np.all(self.ddim_sigmas[:total_steps] == 0.))
-        if x.is_cuda and eta_zero and total_steps > 0:
+        # noise_dropout > 0 (reference ddim.py:167-169 / :294-296: F.dropout on the step noise) draws a mask from the device
+        # generator on every step, between the noise draws: that order only exists in the eager loop
+        if x.is_cuda and eta_zero and total_steps > 0 and not noise_dropout > 0.:
             x, pred_x0 = self._loop_static(x, x_info, c_info_list, time_range, total_steps, guided, scale, _single,
                                            log_every_t, intermediates, dtype)
         else:
             pred_x0 = None
             for i, step in enumerate(time_range):
                 index = total_steps - i - 1
-                x, pred_x0 = self._step(x, x_info, c_info_list, int(step), index, guided, scale, temperature, _single)
+                x, pred_x0 = self._step(x, x_info, c_info_list, int(step), index, guided, scale, temperature, _single,
+                                        noise_dropout=noise_dropout)
                 if index % log_every_t == 0 or index == total_steps - 1:
                     intermediates["pred_xt"].append(x.to(dtype))
                     intermediates["pred_x0"].append(pred_x0.to(dtype))
@@ -267,7 +269,7 @@ class DDIMSampler(object):
             self.use_graph = False
             return None
 
-    def _step(self, x, x_info, c_info_list, step, index, guided, scale, temperature, single):
+    def _step(self, x, x_info, c_info_list, step, index, guided, scale, temperature, single, noise_dropout=0.):
         """One p_sample_ddim (reference ddim.py:129-171 / 244-298) on the fp16 device latent `x` [B,C,H,W]."""
         b = x.shape[0]
         nb = 2 * b if guided else b
@@ -281,6 +283,10 @@ class DDIMSampler(object):
         # drawn on every step like the reference's noise_like(x) (ddim.py:167 there): same generator consumption, and for
         # eta > 0 the same noise values as a reference running in fp16 on this device
         noise = torch.randn_like(x)
+        if noise_dropout > 0.:
+            # reference: noise = dropout(sigma_t * noise_like(x) * temperature, p) -- the mask (and its 1 / (1 - p) scale)
+            # commutes with the scalar factors, so it is applied to the unit noise; drawn even at sigma = 0, like there
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         if sigma != 0.:
             noise = noise if temperature == 1. else (noise.float() * temperature).to(torch.float16)
         else:
@@ -301,7 +307,7 @@ class DDIMSampler(object):
         ci["c"] = torch.cat([c_info["unconditional_conditioning"], c_info["conditioning"]]) if guided else c_info["conditioning"]
         x = x_info["x"]
         xp, p0 = self._step(x.to(torch.float16).contiguous(), x_info, [ci], int(t[0]), index, guided, scale,
-                            temperature, True)
+                            temperature, True, noise_dropout=noise_dropout)
         return xp.to(x.dtype), p0.to(x.dtype)
 
     @torch.no_grad()
@@ -318,5 +324,5 @@ class DDIMSampler(object):
             cis.append(ci)
         x = x_info["x"]
         xp, p0 = self._step(x.to(torch.float16).contiguous(), x_info, cis, int(t[0]), index, guided, scale,
-                            temperature, False)
+                            temperature, False, noise_dropout=noise_dropout)
         return xp.to(x.dtype), p0.to(x.dtype)

@@ -64,7 +64,8 @@ class Conv2d(nn.Conv2d, PackCache):
 
     forward(x, x1=None, ups=0, pad_hi=None, **epilogue): x1 is an optional second tensor whose channels are
     concatenated after x's (never materialised); ups=1 fuses a nearest 2x upsample in front; epilogue keywords
-    (rowvec/rows_per_batch/res/act/alpha) are fused into the GEMM epilogue."""
+    (rowvec/rows_per_batch/res/act/alpha) are fused into the GEMM epilogue.  want_stats=True: the output feeds a GroupNorm --
+    its producer emits the per-channel statistics (ops.ChanStats on the returned tensor, csrc/gn_fused.hip)."""
 
     def _w(self):
         def build():
@@ -85,8 +86,12 @@ class Conv2d(nn.Conv2d, PackCache):
             assert x1 is None and ups == 0
             a, (B, Ho, Wo) = ops.im2col_small(x, layout=in_layout, ksize=k, stride=s, pad=p, pad_hi=pad_hi,
                                               in_scale=in_scale, in_shift=in_shift)
-            out = ops.gemm(a, w, bias=b, **epi)
-            return out.view(B, Ho, Wo, self.out_channels)
+            out = ops.gemm(a, w, bias=b, stat_img_rows=Ho * Wo, **epi)
+            st = ops.stats_of(out)
+            out = out.view(B, Ho, Wo, self.out_channels)
+            if st is not None:
+                out._vd_stats = st
+            return out
         assert in_layout == "nhwc" and in_scale == 1.0 and in_shift == 0.0
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=s, pad=p, ups=ups, x1=x1, pad_hi=pad_hi, **epi)
 

@@ -79,7 +79,7 @@ class Upsample(nn.Module):
         self.conv = Conv2d(self.channels, self.out_channels, 3, padding=padding)
 
     def forward(self, x):
-        return self.conv(x, ups=1)  # nearest 2x folded into the conv's gather
+        return self.conv(x, ups=1, want_stats=True)  # nearest 2x folded into the conv's gather; feeds a ResBlock's GroupNorm
 
 
 class Downsample(nn.Module):
@@ -92,7 +92,7 @@ class Downsample(nn.Module):
         self.op = Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
 
     def forward(self, x):
-        return self.op(x)
+        return self.op(x, want_stats=True)
 
 
 # development switch (VD_RES_FORK=1): the skip 1x1 convolution of a ResBlock on a side stream beside the block's main path.
@@ -153,8 +153,10 @@ class ResBlock(TimestepBlock, PackCache):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self.skip_connection(x, x1=skip, out=res)
+        # every tensor between the layers of the data flow feeds a GroupNorm (the next block's, or a later skip concat): its
+        # producer emits the per-channel statistics (want_stats), the norms read them instead of measuring their input
         h = self.in_layers[0](x, x1=skip, silu=True)
-        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W, bias=bias1)
+        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W, bias=bias1, want_stats=True)
         h = self.out_layers[0](h, silu=True)
         if fork:
             main.wait_stream(side)
@@ -163,7 +165,7 @@ class ResBlock(TimestepBlock, PackCache):
             res = x
         else:
             res = self.skip_connection(x, x1=skip)
-        return self.out_layers[3](h, res=res)
+        return self.out_layers[3](h, res=res, want_stats=True)
 
 
 class OutputHead(nn.Sequential):
@@ -180,7 +182,7 @@ class InputConv(Conv2d):
     """First data layer: 3x3 conv on the NCHW latent the sampler hands over (small-Cin im2col + MFMA GEMM)."""
 
     def forward(self, x):
-        return super().forward(x, in_layout="nchw")
+        return super().forward(x, in_layout="nchw", want_stats=True)
 
 
 @register("openai_unet_2d_next")

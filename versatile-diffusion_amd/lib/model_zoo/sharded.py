@@ -18,8 +18,18 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def draw_initial_latent(shape, seed, dtype=torch.float32):
-    """Full-batch x_T from the host generator with the reference's seed convention; identical on every rank."""
+def draw_initial_latent(shape, seed, dtype=torch.float32, device_generator=False, device=None):
+    """Full-batch x_T with the reference's seed convention (`seed + 100`, app.py:309).
+
+    Default: from a HOST generator -- identical on every rank and for every world size, but NOT the numbers the
+    reference's unsharded call draws (it seeds the global generator and draws `torch.randn(shape, device=cuda,
+    dtype=fp16)` on the device, ddim.py:105).  device_generator=True reproduces exactly that draw (global
+    `torch.manual_seed(seed + 100)`, then randn on `device` in `dtype`): a single-rank sharded run then starts from the
+    same x_T as `DDIMSampler.sample(x_info={'type': 'image'})` after the app's seeding.  Device RNG streams depend on
+    the tensor's shape, so this mode is only offered for the whole batch on one rank (world size 1)."""
+    if device_generator:
+        torch.manual_seed(int(seed) + 100)
+        return torch.randn(tuple(shape), device=device, dtype=dtype)
     g = torch.Generator(device="cpu").manual_seed(int(seed) + 100)
     return torch.randn(tuple(shape), generator=g, dtype=torch.float32).to(dtype)
 
@@ -31,7 +41,7 @@ def _slice_ctx(c_info, lo, hi):
     return out
 
 
-def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group=None, gather=True):
+def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group=None, gather=True, device_generator=False):
     """Run `sample_fn(x_T_local, c_info_list_local) -> latents` and `decode_fn(latents) -> images` on this rank's slice
     of the batch and all_gather the images.
 
@@ -45,7 +55,12 @@ def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group
     if torch.device(device).type == "cuda":
         torch.cuda.set_device(device)  # kernels and the RCCL communicator of this rank live on its own GPU
     lo, hi = shard_bounds(B, world, rank)
-    x_T = draw_initial_latent(shape, seed)[lo:hi].to(device)
+    if device_generator:
+        if world != 1:
+            raise ValueError("sample_sharded: device_generator=True reproduces the unsharded sampler's x_T and needs world size 1")
+        x_T = draw_initial_latent(shape, seed, dtype=torch.float16, device_generator=True, device=device)
+    else:
+        x_T = draw_initial_latent(shape, seed)[lo:hi].to(device)
     local_ctx = [_slice_ctx(ci, lo, hi) for ci in c_info_list]
     images = decode_fn(sample_fn(x_T, local_ctx))
     if world == 1 or not gather:
@@ -65,7 +80,7 @@ def sample_sharded(sample_fn, decode_fn, shape, c_info_list, seed, device, group
 
 
 def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_scale=7.5, eta=0., group=None,
-                      images=None, fidelity=0.):
+                      images=None, fidelity=0., device_generator=False):
     """t2i / image-variation / multi-context sampling + kl-f8 decode of a full batch, sharded over the process group.
 
     images + fidelity > 0: image variation with fidelity (reference app.py:355-371) -- `images` is THIS RANK's slice of
@@ -97,4 +112,4 @@ def vd_sample_sharded(net, sampler, steps, shape, c_info_list, seed, guidance_sc
         return z
 
     return sample_sharded(sample_fn, lambda z: net.vae_decode(z, which="image"), shape, c_info_list, seed, net.device,
-                          group=group)
+                          group=group, device_generator=device_generator)

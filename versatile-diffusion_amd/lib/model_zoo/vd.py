@@ -89,7 +89,7 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
                 h = blk(h, emb_silu, None, emb_out=eo)
         elif ltype == "c":
             if shared:  # the replicas diverge here
-                rep = lambda t: t.repeat(repeat, *([1] * (t.dim() - 1)))
+                rep = lambda t: ops.repeat_batch(t, repeat)   # per-channel statistics of the tensors travel along
                 h, hs, shared = rep(h), [rep(t) for t in hs], False
             h = run_context(h)
         elif ltype == "save_hidden_feature":

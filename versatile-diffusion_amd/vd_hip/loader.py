@@ -27,6 +27,7 @@ class VdGemmDesc(ctypes.Structure):
         ("stride_res", ctypes.c_int64),
         ("colsum", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
         ("sync", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p),
+        ("out_stats", ctypes.c_void_p), ("stat_img_rows", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
 
 
@@ -37,6 +38,7 @@ PROTOTYPES = {
     "vd_gemm_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P]),
     "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "vd_gemm_stat_rows": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_config_name": (ctypes.c_char_p, [_I]),
     "vd_gemm_num_configs": (_I, []),
     "vd_gemm_set_override": (_I, [_I]),
@@ -51,6 +53,10 @@ PROTOTYPES = {
     "vd_gemm_tune_clear": (_I, []),
     "vd_groupnorm_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "vd_groupnorm_from_stats_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "vd_chan_stats_f16": (_I, [_P, ctypes.c_long, _I, _I, _I, _P, _P]),
+    "vd_gn_table_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P]),
+    "vd_gn_apply_table_f16": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vd_row_stats_f16": (_I, [_P, _P, _L, _I, _L, _F, _P]),

@@ -12,7 +12,7 @@ import torch
 
 from .loader import VdGemmDesc, VdHipError, lib
 
-EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD, EPI_LN_INLOOP = 1, 2, 4, 8, 16, 32, 64
 ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 _ws_cache = {}
@@ -137,9 +137,34 @@ def row_stats(x, C, rows, eps, ldx=None):
     return stats
 
 
+class ChanStats(object):
+    """Per-channel partial statistics of a tensor, emitted by its producer (VdGemmDesc.out_stats) or by chan_stats():
+    buf fp32 [B * T, C, 2] = (mean, M2) over T blocks of HW / T rows per sample.  Travels as the attribute `_vd_stats` of the
+    tensor it describes; views / copies do not carry it (the consumer then measures the tensor itself)."""
+    __slots__ = ("buf", "T", "C", "HW")
+
+    def __init__(self, buf, T, C, HW):
+        self.buf, self.T, self.C, self.HW = buf, int(T), int(C), int(HW)
+
+
+def stats_of(t):
+    """ChanStats attached to tensor `t` by its producer, or None."""
+    return getattr(t, "_vd_stats", None) if t is not None else None
+
+
+def repeat_batch(t, repeat):
+    """t.repeat(repeat, 1, ...) on the batch axis, statistics included (the CFG replicas of run_unet)."""
+    out = t.repeat(repeat, *([1] * (t.dim() - 1)))
+    st = stats_of(t)
+    if st is not None:
+        out._vd_stats = ChanStats(st.buf.repeat(repeat, 1, 1), st.T, st.C, st.HW)
+    return out
+
+
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
-         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None):
+         lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
+         want_stats=False, stat_img_rows=0):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -148,13 +173,17 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     (hip_layers.fold_layernorm).
     fixup=True: split-K slabs are summed by the last-arriving block of each tile (VdGemmDesc.sync) instead of the reduce
     kernel; default from VD_GEMM_FIXUP (off: the in-kernel tail measured 0.2 ms per UNet forward slower than the launch).
+    want_stats=True: the producing epilogue (or the split-K reduce) also emits per-channel partial statistics of the stored
+    output for a consuming GroupNorm (VdGemmDesc.out_stats); they come back as `out._vd_stats` (ChanStats) when the planned
+    launch can emit them, else the attribute is absent.  stat_img_rows: rows of one sample for plain matrices (conv: Hout*Wout).
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
     # (the plain N = 320 projections measure equal on both kernels -- 24.9 vs 24.2 us: with one 128-row block per CU in
     # lock-step a launch is its load / store phases either way; the LayerNorm-folded q | k | v projection is 59 vs 66 us + the
     # statistics launch)
-    if ROW320 and colsum is not None and _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k):
+    if ROW320 and colsum is not None and _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k,
+                                                    c0, c1, strides, fixup, rows_per_batch):
         return gemm_row320(a0, w, bias, res, True, ln_eps, out_shape)
     if not _tune_checked[0]:     # shipped tuned launch table (vd_hip/tune.py), installed on first use
         _tune_checked[0] = True
@@ -203,6 +232,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if not LN_INLOOP:   # two-pass statistics from their own launch instead of the K loop's running sums
             ln_stats = row_stats(a0, int(K), int(M), float(ln_eps), ldx=int(lda0) if lda0 else int(K))
             d.ln_stats = ln_stats.data_ptr()
+        else:
+            flags |= EPI_LN_INLOOP
     d.flags, d.act, d.alpha = flags, int(act), float(alpha)
     d.batch, d.split_k = int(batch), int(split_k)
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = [int(s) for s in strides]
@@ -227,6 +258,16 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             use_sync = HALO_FIXUP if halo else (FIXUP_DEFAULT if fixup is None else fixup)
             d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+    stats = None
+    if want_stats and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
+        d.stat_img_rows = int(stat_img_rows)
+        rows = ctypes.c_int(0)
+        _check(lib().vd_gemm_stat_rows(ctypes.byref(d), ctypes.byref(rows)))
+        if rows.value > 0:
+            hw = int(stat_img_rows) if stat_img_rows else (int(d.Hout) * int(d.Wout) if conv is not None else int(M))
+            sbuf = torch.empty((int(M) // rows.value, n_out, 2), dtype=torch.float32, device=a0.device)
+            d.out_stats = sbuf.data_ptr()
+            stats = ChanStats(sbuf, hw // rows.value, n_out, hw)
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         name = gemm_kernel_name(plan_cfg.value)
@@ -243,15 +284,21 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
     with _Timed(name, 2.0 * nb * M * N * K, 2.0 * (nb * (a_elems + float(N) * K + float(M) * n_out) + extra)):
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
+    if stats is not None:
+        out._vd_stats = stats
     return out
 
 
 ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
 
 
-def _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k):
-    """vd_gemm_row320_f16 takes the plain K = 320 projections whose row blocks fill the chip (the UNet's 64x64 level)."""
+def _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, bias_along_m, batch, lda0, ldw, ldc, ldr, split_k,
+               c0=0, c1=0, strides=(0, 0, 0, 0), fixup=None, rows_per_batch=0):
+    """vd_gemm_row320_f16 takes the plain K = 320 projections whose row blocks fill the chip (the UNet's 64x64 level).
+    Every argument of gemm() the row-resident kernel has no notion of must be at its neutral value."""
     if a1 is not None or rowvec is not None or out is not None or out_f32 or bias_along_m or max(batch, 1) != 1:
+        return False
+    if int(c0) not in (0, 320) or int(c1) != 0 or any(int(v) != 0 for v in strides) or fixup or int(rows_per_batch) != 0:
         return False
     if act != ACT_NONE or alpha != 1.0 or split_k > 1 or w.dim() != 2 or not w.is_contiguous() or not a0.is_contiguous():
         return False
@@ -271,7 +318,9 @@ def _row320_ok(a0, w, a1, rowvec, res, out, M, N, K, conv, act, alpha, out_f32, 
         return False
     if res is not None and (not res.is_contiguous() or res.numel() != m * n):
         return False
-    return ((m + 127) // 128) * (n // 320) >= 192
+    # one 128-row block per CU: worth it when the row blocks cover at least 3/4 of the device's CUs
+    cus = torch.cuda.get_device_properties(a0.device).multi_processor_count if a0.is_cuda else 256
+    return ((m + 127) // 128) * (n // 320) >= (3 * cus) // 4
 
 
 def gemm_row320(a0, w, bias=None, res=None, layernorm=False, ln_eps=1e-5, out_shape=None):
@@ -386,6 +435,12 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
     c1 = x1.shape[-1] if x1 is not None else 0
     HW = x.numel() // (B * c0)
     C = c0 + c1
+    if GN_STATS and _from_stats_ok(C, groups) and x.is_contiguous() and (x1 is None or x1.is_contiguous()):
+        st0, st1 = stats_of(x), stats_of(x1)
+        if st0 is not None or st1 is not None:   # a source without producer statistics is measured with one read of it alone
+            st0 = st0 if st0 is not None else chan_stats(x)
+            st1 = st1 if (st1 is not None or x1 is None) else chan_stats(x1)
+            return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
     if out is None:
         out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
     nb = lib().vd_groupnorm_workspace_bytes(B, HW, C, groups)
@@ -393,6 +448,75 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
     with _Timed("groupnorm (slab kernel or partial+apply)", 0.0, 2.0 * B * HW * C * 3):
         _check(lib().vd_groupnorm_silu_f16(_ptr(x), c0, _ptr(x1), c1, _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), B, HW,
                                            groups, float(eps), 1 if silu else 0, _stream()))
+    return out
+
+
+# VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
+# come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
+GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
+
+
+def _from_stats_ok(C, groups):
+    """Slab of vd_groupnorm_from_stats_f16: lcm(channels per group, 8) channels = at most 8 whole groups, dividing C."""
+    if C % groups != 0 or C % 8 != 0:
+        return False
+    cg = C // groups
+    s = cg
+    while s % 8:
+        s += cg
+    return C % s == 0 and s // cg <= 8 and s // 8 <= 256
+
+
+def chan_stats(x, rows_per_partial=None):
+    """Per-channel partial statistics of channels-last x [B, ..., C] with one read of x (the producers' out_stats format)."""
+    _req(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    if rows_per_partial is None:
+        rows_per_partial = 256 if HW % 256 == 0 else (64 if HW % 64 == 0 else HW)
+    T = HW // rows_per_partial
+    buf = torch.empty((B * T, C, 2), dtype=torch.float32, device=x.device)
+    with _Timed("chan_stats_kernel", 0.0, 2.0 * B * HW * C):
+        _check(lib().vd_chan_stats_f16(_ptr(x), B * HW, C, C, int(rows_per_partial), _ptr(buf), _stream()))
+    return ChanStats(buf, T, C, HW)
+
+
+def groupnorm_from_stats(x, gamma, beta, st0, *, x1=None, st1=None, groups=32, eps=1e-5, silu=True, out=None):
+    """GroupNorm(+SiLU) over channels-last x (++ x1) from per-channel partial statistics: one launch, x read once."""
+    _req(x, "x"); _req(x1, "x1"); _req(gamma, "gamma"); _req(beta, "beta")
+    B = x.shape[0]
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x.numel() // (B * c0)
+    C = c0 + c1
+    if st0.C != c0 or st0.HW != HW or st0.buf.shape[0] != B * st0.T or (x1 is not None and (st1 is None or st1.C != c1 or st1.HW != HW or st1.buf.shape[0] != B * st1.T)):
+        raise VdHipError("groupnorm_from_stats: statistics do not describe the input tensors")
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
+    with _Timed("gn_from_stats_kernel", 0.0, 2.0 * B * HW * C * 2):
+        _check(lib().vd_groupnorm_from_stats_f16(_ptr(x), c0, _ptr(st0.buf), st0.T, _ptr(x1), c1, _ptr(st1.buf) if st1 is not None else None,
+                                                 st1.T if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(out), B, HW, groups,
+                                                 float(eps), 1 if silu else 0, _stream()))
+    return out
+
+
+def gn_table(st0, gamma, beta, *, st1=None, B, groups=32, eps=1e-5):
+    """Partial statistics -> fp32 [B, 2, C] (scale, shift) of the GroupNorm as a per-(sample, channel) affine map."""
+    C = st0.C + (st1.C if st1 is not None else 0)
+    table = torch.empty((B, 2, C), dtype=torch.float32, device=st0.buf.device)
+    _check(lib().vd_gn_table_f32(_ptr(st0.buf), st0.T, st0.C, _ptr(st1.buf) if st1 is not None else None, st1.T if st1 is not None else 0,
+                                 st1.C if st1 is not None else 0, B, st0.HW, _ptr(gamma), _ptr(beta), groups, float(eps), _ptr(table), _stream()))
+    return table
+
+
+def gn_apply_table(x, table, *, x1=None, silu=True):
+    """y = act(cat(x, x1) * scale + shift) with the fp32 [B, 2, C] table of gn_table()."""
+    _req(x, "x"); _req(x1, "x1")
+    B, c0 = x.shape[0], x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x.numel() // (B * c0)
+    out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x.device)
+    _check(lib().vd_gn_apply_table_f16(_ptr(x), c0, _ptr(x1), c1, B, HW, _ptr(table), 1 if silu else 0, _ptr(out), _stream()))
     return out
 
 
