@@ -924,9 +924,8 @@ def test_groupnorm_from_stats(ops, dev, B, HW, c0, c1, R0, R1, silu, eps):
     x0._vd_stats = st0
     out3 = ops.groupnorm_silu(x0, gamma, beta, x1=x1, groups=32, eps=eps, silu=silu)
     assert rel_l2(out3, ref) < 2e-3
-    if ops.GN_STATS:
-        assert torch.equal(out3, ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=ops.chan_stats(x1) if c1 else None,
-                                                          groups=32, eps=eps, silu=silu)) or c1   # same kernel, same partials
+    if ops.GN_STATS and not c1 and ops.GN_FORM == "table":
+        assert torch.equal(out3, out2)   # the dispatch took the statistics on the tensor: same kernels, same partials
     # run-to-run identical (no atomics)
     assert torch.equal(out, ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu))
 

@@ -808,9 +808,10 @@ def test_sharded_device_generator_reproduces_unsharded_sampler(tiny, dev):
     z, _ = DDIMSampler(tiny).sample(steps=steps, shape=shape, x_info={"type": "image"},
                                     c_info=dict(ct, unconditional_guidance_scale=7.5), eta=0., verbose=False)
     ref = tiny.vae_decode(z, which="image")
-    assert torch.equal(img, ref)
+    # same x_T, same kernels; not bit-equal from run to run (GroupNorm partial sums meet through LDS float atomics)
+    assert rel_l2(img, ref) < 2e-3
     img_host = sharded.vd_sample_sharded(tiny, DDIMSampler(tiny), steps, shape, [dict(ct)], seed)
-    assert not torch.equal(img_host, ref)
+    assert rel_l2(img_host, ref) > 5e-2   # another x_T altogether
 
 
 def test_c2_shape_guided_10_step_loop_batch2_vs_oracle(full, dev, monkeypatch):

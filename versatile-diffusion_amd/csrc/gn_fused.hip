@@ -147,29 +147,56 @@ __global__ __launch_bounds__(256) void gn_table_kernel(const GnTableArgs a) {
 }
 
 // ---- 3. elementwise consumer: out[b][p][c] = act(x[b][p][c] * scale[b][c] + shift[b][c]), x = cat(x0, x1) on channels ----
-__global__ __launch_bounds__(256) void gn_apply_table_kernel(const f16* __restrict__ x0, int c0, const f16* __restrict__ x1, int c1,
-                                                             const float* __restrict__ table, int HW, size_t total8, int silu,
-                                                             f16* __restrict__ out) {
-    const int C = c0 + c1, C8 = C / 8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / C8;
-        const int ch = (int)(i - row * C8) * 8;
-        const int b = (int)(row / HW);
-        const f16* src = ch < c0 ? x0 + row * c0 + ch : x1 + row * c1 + (ch - c0);
-        U4H8 v, o;
-        v.u = *reinterpret_cast<const uint4*>(src);
-        const float4 s0 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2) * C + ch);
-        const float4 s1 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2) * C + ch + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2 + 1) * C + ch);
-        const float4 h1 = *reinterpret_cast<const float4*>(table + ((size_t)b * 2 + 1) * C + ch + 4);
+// A thread keeps ONE channel octet (two where C > 2048) for all its rows, so scale / shift are read once per block and the
+// row loop is a 16-byte load, 8 FMAs (+ SiLU) and a 16-byte store; consecutive threads cover a whole row (full cache
+// lines).  grid (row chunks, B), 256 threads = TC channel octets x R row lanes.
+struct GnApplyArgs {
+    const f16* x0; const f16* x1; const float* table; f16* out;
+    int c0, c1, HW, TC, R, npos, rows_per_chunk, silu;
+};
+
+__global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a) {
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int C = a.c0 + a.c1, C8 = C / 8;
+    const int tc = tid % a.TC, rl = tid / a.TC;
+    if (rl >= a.R) return;
+    const int r0 = blockIdx.x * a.rows_per_chunk;
+    int r1 = r0 + a.rows_per_chunk;
+    if (r1 > a.HW) r1 = a.HW;
+    const size_t rowb = (size_t)b * a.HW;
+    for (int pos = 0; pos < a.npos; ++pos) {
+        const int cc = tc + pos * a.TC;
+        if (cc >= C8) break;
+        const int ch = cc * 8;
+        const float* tb = a.table + ((size_t)b * 2) * C + ch;
+        const float4 s0 = *reinterpret_cast<const float4*>(tb), s1 = *reinterpret_cast<const float4*>(tb + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(tb + C), h1 = *reinterpret_cast<const float4*>(tb + C + 4);
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float sf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const bool second = ch >= a.c0;
+        const f16* src = second ? a.x1 + (ch - a.c0) : a.x0 + ch;
+        const int ld = second ? a.c1 : a.c0;
+        for (int r = r0 + rl; r < r1; r += 4 * a.R) {   // 4 loads in flight
+            U4H8 t[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float y = fmaf((float)v.e[q], sc[q], sf[q]);
-            o.e[q] = (f16)(silu ? vd_silu(y) : y);
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * a.R;
+                t[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : r)) * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * a.R;
+                if (ru < r1) {
+                    U4H8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float y = fmaf((float)t[u].e[q], sc[q], sf[q]);
+                        o.e[q] = (f16)(a.silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y)) : y);
+                    }
+                    *reinterpret_cast<uint4*>(a.out + (rowb + ru) * C + ch) = o.u;
+                }
+            }
         }
-        *reinterpret_cast<uint4*>(out + row * C + ch) = o.u;
     }
 }
 
@@ -365,11 +392,21 @@ extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int
                                      void* out, hipStream_t stream) {
     VD_REQUIRE(x0 && table && out, "vd_gn_apply_table_f16: null pointer");
     if (!x1) c1 = 0;
-    VD_REQUIRE(B > 0 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
-    const size_t total8 = (size_t)B * HW * ((c0 + c1) / 8);
-    size_t blocks = (total8 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gn_apply_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const f16*>(x0), c0,
-                       reinterpret_cast<const f16*>(x1), c1, table, HW, total8, silu, reinterpret_cast<f16*>(out));
+    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
+    const int C = c0 + c1, C8 = C / 8;
+    VD_REQUIRE(C8 <= 512, "vd_gn_apply_table_f16: C=%d > 4096", C);
+    GnApplyArgs a;
+    a.x0 = reinterpret_cast<const f16*>(x0); a.x1 = reinterpret_cast<const f16*>(x1); a.table = table; a.out = reinterpret_cast<f16*>(out);
+    a.c0 = c0; a.c1 = c1; a.HW = HW; a.silu = silu;
+    a.TC = C8 < 256 ? C8 : 256;
+    a.R = 256 / a.TC;
+    a.npos = (C8 + a.TC - 1) / a.TC;
+    // ~16K elements per block (the optimum the round-3 apply kernel measured), whole row-lane trips
+    int rpc = 16384 / C;
+    if (rpc < 1) rpc = 1;
+    rpc = ((rpc + a.R - 1) / a.R) * a.R;
+    if (rpc > HW) rpc = HW;
+    a.rows_per_chunk = rpc;
+    hipLaunchKernelGGL(gn_apply_table_kernel, dim3((HW + rpc - 1) / rpc, B), dim3(256), 0, stream, a);
     return vd_check_launch("vd_gn_apply_table_f16");
 }

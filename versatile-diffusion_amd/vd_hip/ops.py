@@ -440,7 +440,12 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
         if st0 is not None or st1 is not None:   # a source without producer statistics is measured with one read of it alone
             st0 = st0 if st0 is not None else chan_stats(x)
             st1 = st1 if (st1 is not None or x1 is None) else chan_stats(x1)
-            return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
+            if GN_FORM == "fused":   # one launch (block-local fold of the partials, slab-shaped panels)
+                return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
+            # default: a tiny launch folds the partials into the per-(sample, channel) affine map, the apply launch streams
+            # whole rows (measured: the slab-shaped single launch reads 80-byte pieces and ran no faster than the old pair)
+            table = gn_table(st0, gamma, beta, st1=st1, B=B, groups=groups, eps=eps)
+            return gn_apply_table(x, table, x1=x1, silu=silu, out=out)
     if out is None:
         out = torch.empty(x.shape[:-1] + (C,), dtype=torch.float16, device=x.device)
     nb = lib().vd_groupnorm_workspace_bytes(B, HW, C, groups)
@@ -454,6 +459,7 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
 # VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
 # come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
 GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
+GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
 
 def _from_stats_ok(C, groups):
@@ -504,19 +510,23 @@ def gn_table(st0, gamma, beta, *, st1=None, B, groups=32, eps=1e-5):
     """Partial statistics -> fp32 [B, 2, C] (scale, shift) of the GroupNorm as a per-(sample, channel) affine map."""
     C = st0.C + (st1.C if st1 is not None else 0)
     table = torch.empty((B, 2, C), dtype=torch.float32, device=st0.buf.device)
-    _check(lib().vd_gn_table_f32(_ptr(st0.buf), st0.T, st0.C, _ptr(st1.buf) if st1 is not None else None, st1.T if st1 is not None else 0,
-                                 st1.C if st1 is not None else 0, B, st0.HW, _ptr(gamma), _ptr(beta), groups, float(eps), _ptr(table), _stream()))
+    with _Timed("gn_table_kernel", 0.0, 0.0):
+        _check(lib().vd_gn_table_f32(_ptr(st0.buf), st0.T, st0.C, _ptr(st1.buf) if st1 is not None else None,
+                                     st1.T if st1 is not None else 0, st1.C if st1 is not None else 0, B, st0.HW, _ptr(gamma), _ptr(beta),
+                                     groups, float(eps), _ptr(table), _stream()))
     return table
 
 
-def gn_apply_table(x, table, *, x1=None, silu=True):
+def gn_apply_table(x, table, *, x1=None, silu=True, out=None):
     """y = act(cat(x, x1) * scale + shift) with the fp32 [B, 2, C] table of gn_table()."""
     _req(x, "x"); _req(x1, "x1")
     B, c0 = x.shape[0], x.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
     HW = x.numel() // (B * c0)
-    out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x.device)
-    _check(lib().vd_gn_apply_table_f16(_ptr(x), c0, _ptr(x1), c1, B, HW, _ptr(table), 1 if silu else 0, _ptr(out), _stream()))
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x.device)
+    with _Timed("gn_apply_table_kernel", 0.0, 2.0 * B * HW * (c0 + c1) * 2):
+        _check(lib().vd_gn_apply_table_f16(_ptr(x), c0, _ptr(x1), c1, B, HW, _ptr(table), 1 if silu else 0, _ptr(out), _stream()))
     return out
 
 
