@@ -140,6 +140,18 @@ int vd_conv_halo_set_variant(int setting);
  * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table
  * (lib/gemm_tune.py) from a file tools/tune_forward.py measured inside a UNet forward -- the setting that decides, since
  * weights then stream from HBM and activations come hot from the previous kernel.  Thread-safe. */
+/* The 3x3 / stride 1 / pad 1 convolutions on 8x8 images (the ResBlocks at ds = 8: lib/model_zoo/openaimodel.py:254-274 with
+ * 1280 / 2560 input channels) as a WEIGHT-STREAMING kernel: M = images x 64 is tiny, the layer is its 29.5 / 59 MB weight
+ * stream.  `desc` as for vd_gemm_f16 (its `w` is not read; `ws` must hold vd_gemm_workspace_bytes); `w_stream` holds the same
+ * weights in MFMA-fragment order, fp16 [N / 32][(c0 + c1) / 64][9 taps][4 k-steps][64 lanes][8]: lane l of the fragment of
+ * (n tile t, chunk c, tap, k-step s) holds W[32 t + (l & 31)][tap][64 c + 16 s + 8 (l >> 5) .. + 8] (vd_hip/pack.py:
+ * pack_conv_weight_stream) -- every A operand of an MFMA is one coalesced 1-KiB load straight into registers, the input halo
+ * of a chunk is staged in LDS once, K is split over chunks (fp32 slabs + the reduce kernel, which runs desc's epilogue and
+ * emits desc->out_stats in partials of 64 rows when asked).  vd_conv3x3_wstream_supported: 1 when desc's geometry fits. */
+int vd_conv3x3_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
+int vd_conv3x3_wstream_supported(const VdGemmDesc* desc);
+/* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */
+int vd_conv3x3_wstream_set_variant(int variant, int target_blocks);
 int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
 int vd_gemm_tune_clear(void);
 

@@ -998,3 +998,49 @@ def test_gemm_out_stats(ops, dev, case):
     refn = F.silu(F.group_norm(o3.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
     got = ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True)
     assert rel_l2(got, refn) < 2e-3
+
+
+@pytest.mark.parametrize("case", [
+    # B, c0, c1, Co, rowvec, residual
+    (8, 1280, 0, 1280, True, False),      # ResBlock in-conv at ds = 8 (bench shape)
+    (8, 1280, 1280, 1280, False, True),   # output block: skip concat, residual from the 1x1 skip conv
+    (2, 128, 0, 256, False, False),       # one image pair, one column slice
+    (4, 64, 64, 512, True, True),
+    (6, 192, 0, 256, False, False),       # 3 chunks: ragged split
+])
+def test_conv3x3_wstream(ops, dev, case):
+    """vd_conv3x3_wstream_f16 (weights in MFMA-fragment order streamed into registers, halo in LDS, split over chunks +
+    reduce) against torch's fp32 convolution and against the same problem on gemm_f16_kernel; every instance, several grid
+    targets; statistics of the stored output."""
+    from vd_hip.loader import lib
+    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
+    B, c0, c1, Co, rv, rs = case
+    x = rnd((B, 8, 8, c0), dev, 1.0, 400)
+    x1 = rnd((B, 8, 8, c1), dev, 1.0, 401) if c1 else None
+    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.03, 402)
+    b = rnd((Co,), dev, 0.3, 403)
+    ref = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, 0)
+    kw = dict(ksize=3, pad=1, x1=x1)
+    if rv:
+        rowvec = rnd((B, Co), dev, 0.5, 404)
+        kw.update(rowvec=rowvec, rows_per_batch=64)
+        ref = ref + rowvec.float().view(B, 1, 1, Co)
+    if rs:
+        res = rnd((B, 8, 8, Co), dev, 1.0, 405)
+        kw.update(res=res)
+        ref = ref + res.float()
+    wp, wsm = pack_conv_weight(wt), pack_conv_weight_stream(wt)
+    old = ops.conv2d_nhwc(x, wp, b, **kw)
+    assert rel_l2(old, ref) < 2e-3
+    try:
+        for var in range(4):
+            for target in (256, 64, 1024):
+                assert lib().vd_conv3x3_wstream_set_variant(var, target) == 0
+                out = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw)
+                assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, (var, target)
+    finally:
+        lib().vd_conv3x3_wstream_set_variant(0, 256)
+    out = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
+    st = ops.stats_of(out)
+    assert st is not None and st.T == 1 and st.HW == 64
+    _stats_close(st, _chan_stats_ref(out.view(B, 64, Co), B, 1), 64)

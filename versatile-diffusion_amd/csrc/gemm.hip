@@ -618,3 +618,26 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     }
     return VD_OK;
 }
+
+
+// ---- helpers for conv_wstream.hip (its own translation unit: other compiler flags) ---------------------------------------
+// validate + normalise `desc` exactly as vd_gemm_f16 does; gemm_args_out: a GemmArgs
+int vd_gemm_normalise(const VdGemmDesc* desc, void* gemm_args_out) {
+    int cfg = 0, ns = 1;
+    return plan_gemm(desc, *static_cast<GemmArgs*>(gemm_args_out), cfg, ns);
+}
+// sum `nsplit` fp32 slabs of d.ws and run the fused epilogue of the (normalised) descriptor; with d.out_stats also the
+// per-channel statistics in partials of 64 rows
+int vd_gemm_launch_reduce(const void* gemm_args, int nsplit, hipStream_t stream) {
+    const GemmArgs& a = *static_cast<const GemmArgs*>(gemm_args);
+    const VdGemmDesc& d = a.d;
+    if (d.out_stats != nullptr) {
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+        return vd_check_launch("splitk_reduce_stats");
+    }
+    const size_t total = (size_t)d.M * ((d.N + 7) / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1, 1), dim3(256), 0, stream, a, nsplit);
+    return vd_check_launch("splitk_reduce");
+}

@@ -76,6 +76,10 @@ class Conv2d(nn.Conv2d, PackCache):
             return pack.pack_conv_weight(w), _h(self.bias)
         return self._packed("w", (self.weight, self.bias), build)
 
+    def _w_stream(self):
+        """MFMA-fragment-ordered copy of the 3x3 weights for the weight-streaming kernel of the 8x8 level."""
+        return self._packed("w_stream", (self.weight,), lambda: pack.pack_conv_weight_stream(_h(self.weight)))
+
     def forward(self, x, x1=None, ups=0, pad_hi=None, in_layout="nhwc", in_scale=1.0, in_shift=0.0, bias=None, **epi):
         w, b = self._w()
         if bias is not None:  # caller-supplied (pre-combined) bias vector
@@ -93,6 +97,9 @@ class Conv2d(nn.Conv2d, PackCache):
                 out._vd_stats = st
             return out
         assert in_layout == "nhwc" and in_scale == 1.0 and in_shift == 0.0
+        if (ops.WSTREAM and k == 3 and s == 1 and p == 1 and ups == 0 and pad_hi is None and x.shape[1] == 8 and x.shape[2] == 8
+                and x.shape[0] % 2 == 0 and self.out_channels % 256 == 0 and cin % 64 == 0 and x.shape[-1] % 64 == 0):
+            epi = dict(epi, w_stream=self._w_stream())   # 8x8 level: the layer is its weight stream
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=s, pad=p, ups=ups, x1=x1, pad_hi=pad_hi, **epi)
 
 

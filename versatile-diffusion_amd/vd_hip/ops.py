@@ -164,7 +164,7 @@ def repeat_batch(t, repeat):
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
-         want_stats=False, stat_img_rows=0):
+         want_stats=False, stat_img_rows=0, w_stream=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -176,6 +176,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     want_stats=True: the producing epilogue (or the split-K reduce) also emits per-channel partial statistics of the stored
     output for a consuming GroupNorm (VdGemmDesc.out_stats); they come back as `out._vd_stats` (ChanStats) when the planned
     launch can emit them, else the attribute is absent.  stat_img_rows: rows of one sample for plain matrices (conv: Hout*Wout).
+    w_stream: the same conv weights in MFMA-fragment order (pack.pack_conv_weight_stream); 3x3 convolutions on 8x8 images then
+    run on the weight-streaming kernel (vd_conv3x3_wstream_f16) where its geometry fits.
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
@@ -242,6 +244,24 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
+    if w_stream is not None and WSTREAM and colsum is None and lib().vd_conv3x3_wstream_supported(ctypes.byref(d)):
+        _req(w_stream, "w_stream")
+        d.split_k = int(split_k)
+        d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+        stats = None
+        if want_stats:
+            sbuf = torch.empty((int(M) // 64, n_out, 2), dtype=torch.float32, device=a0.device)
+            d.out_stats = sbuf.data_ptr()
+            stats = ChanStats(sbuf, 1, n_out, 64)
+        extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
+        nm = "conv3x3_wstream_kernel + reduce"
+        if PROFILE_SHAPES:
+            nm += " M=%d N=%d K=%d" % (M, N, K)
+        with _Timed(nm, 2.0 * M * N * K, 2.0 * (float(M) * (d.c0 + d.c1) + float(N) * K + float(M) * n_out + extra)):
+            _check(lib().vd_conv3x3_wstream_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
+        if stats is not None:
+            out._vd_stats = stats
+        return out
     # split-K (fp32 slabs + reduce) is the library's answer to small-M / deep-K problems: ask its planner first so
     # the workspace is sized for the split factor it will actually use
     name, d.ws = "gemm", None
@@ -289,6 +309,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     return out
 
 
+WSTREAM = os.environ.get("VD_WSTREAM", "1") != "0"   # development switch: 0 = the 8x8-level 3x3 convolutions stay on gemm_f16_kernel
 ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
 
 

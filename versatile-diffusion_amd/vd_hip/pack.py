@@ -8,6 +8,17 @@ def pack_conv_weight(w):
     return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
 
 
+def pack_conv_weight_stream(w):
+    """torch conv weight [Cout, Cin, 3, 3] -> MFMA-fragment order of vd_conv3x3_wstream_f16:
+    [Cout / 32][Cin / 64][9 taps][4 k-steps][64 lanes][8], lane l of (n tile t, chunk c, tap, k-step s) holding
+    W[32 t + (l & 31)][64 c + 16 s + 8 (l >> 5) .. + 8][tap]: each A operand of an MFMA is one contiguous 1-KiB block."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and co % 32 == 0 and ci % 64 == 0
+    v = w.reshape(co // 32, 32, ci // 64, 4, 2, 8, 3, 3)          # (t, l31, c, s, hi, e, ky, kx)
+    v = v.permute(0, 2, 6, 7, 3, 4, 1, 5)                          # (t, c, ky, kx, s, hi, l31, e)
+    return v.reshape(co // 32, ci // 64, 9, 4, 64, 8).contiguous()
+
+
 def pack_conv_weight_small(w, kpad=None):
     """Same ordering, zero padded along K to a multiple of 64 (matches vd_im2col_small_f16)."""
     p = pack_conv_weight(w)
