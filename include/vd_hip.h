@@ -223,6 +223,11 @@ int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, in
                     const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream);
 int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int apply_silu,
                           void* y, hipStream_t stream);
+/* The same map as fp16 [B][C0 + C1] scale / shift vectors: the gn_scale / gn_shift operands of vd_gemm_row320_chain_f16
+ * (what vd_groupnorm_affine_f16 computes with a pass over x). */
+int vd_gn_affine_from_stats_f16(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
+                                const void* gamma, const void* beta, int groups, float eps, void* scale, void* shift,
+                                hipStream_t stream);
 
 /* GroupNorm(groups) [+ SiLU] of the 0-D (text-latent) data flow: FCBlock normalises the flattened [C, sdim] vector of a
  * sample with one affine pair per flat element (reference openaimodel.py:2084-2141 with the [C, sdim, 1] -> C*sdim view
@@ -374,6 +379,10 @@ int vd_probe_mfma_layout(int32_t* out_a_k, int32_t* out_c_row, int32_t* out_c_co
  * addr_bytes[l] (64 entries) and out[l*4 + j] receives its four 16-bit results; used by tests (the attention kernel's
  * V operand relies on this gather) */
 int vd_probe_lds_tr16(const int32_t* addr_bytes, int16_t* out, hipStream_t stream);
+/* XCD (HW_REG_XCC_ID) of every block of a grid_x x grid_y launch of 256-thread blocks, int32 [grid_y][grid_x]: pins the
+ * dispatcher's round-robin placement (block b of the linearised grid runs on XCD b % 8) that the tile order of the GEMM /
+ * convolution kernels exploits for L2 locality and the ticketed split of conv3x3_halo_kernel relies on. */
+int vd_probe_xcc_ids(int32_t* out, int grid_x, int grid_y, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1044,3 +1044,15 @@ def test_conv3x3_wstream(ops, dev, case):
     st = ops.stats_of(out)
     assert st is not None and st.T == 1 and st.HW == 64
     _stats_close(st, _chan_stats_ref(out.view(B, 64, Co), B, 1), 64)
+
+
+def test_blocks_are_placed_round_robin_over_the_xcds(ops, dev):
+    """Block b of the linearised grid runs on XCD b % 8 (up to a rotation): what the XCD-aware tile orders assume for
+    locality, and what the ticketed split of conv3x3_halo_kernel relies on for CORRECTNESS -- with a tile count that is a
+    multiple of 8, all splits of a tile (same blockIdx.x, any blockIdx.y) share one XCD and hence one L2."""
+    for gx, gy in ((64, 4), (128, 2), (256, 1), (8, 16)):
+        ids = ops.probe_xcc_ids(dev, gx, gy).long()
+        assert ids.min() >= 0 and ids.max() <= 7 and len(set(ids.flatten().tolist())) == 8
+        assert torch.equal(ids, ids[0:1].expand(gy, gx)), "splits of a tile run on different XCDs"
+        rot = (ids[0] - torch.arange(gx)) % 8
+        assert bool((rot == rot[0]).all()), "placement is not round-robin in block order"

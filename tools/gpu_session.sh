@@ -6,6 +6,7 @@
 #   fwd[:ENV=V,ENV=V]              graph-replayed UNet forward at the bench shape (tools/unet_forward.py 3 graph) under the env
 #   shape[:ENV=V,...]              per-shape table of one instrumented forward (tools/shape_profile.py)
 #   bench[:args]                   python bench.py <args>   (commas separate arguments)
+#   ktrace[:ENV=V,...]             rocprofv3 --kernel-trace --stats of 6 eager forwards: per-kernel average durations
 #   trace                          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.csv / breakdown
 #   pmc                            FETCH_SIZE / WRITE_SIZE passes over the forward -> pmc_traffic.json
 #   py:<script and args>           python tools/<script> (commas separate arguments)
@@ -38,6 +39,11 @@ for step in "$@"; do
         NF=$(python tools/count_forwards.py $DB); echo "forwards in the traced run: $NF"
         python tools/kernel_breakdown.py $DB $NF > $O/kernel_breakdown.txt 2>&1; head -30 $O/kernel_breakdown.txt
         rm -rf $O/prof_bench ;;
+    ktrace)   # kernel trace of a few eager forwards (tools/unet_forward.py) under the env: per-kernel average durations
+        (cd /tmp && export TMPDIR=/tmp && envrun "$arg" timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/tools/unet_forward.py 6 > $O/$tag.log 2>&1); echo "rc=$?"
+        DB=$(find $O/prof_$n -name "*.db" | head -1)
+        python tools/kernel_stats.py $DB > $O/$tag.csv 2> $O/$tag.err; head -40 $O/$tag.csv | cut -c1-150
+        rm -rf $O/prof_$n ;;
     pmc)
         (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python $R/tools/unet_forward.py 3 > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
          timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python $R/tools/unet_forward.py 3 > $O/pmc_write.log 2>&1; echo "pmc write rc=$?")

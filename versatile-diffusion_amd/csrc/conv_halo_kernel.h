@@ -490,7 +490,16 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         int* ticket_ctr = d.sync + 2 * tile_id;
         int* done_ctr = ticket_ctr + 1;
         int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) *flag = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // p.g.xcd_local (round 4): the launcher has checked that the blocks of a tile share an XCD (block b runs on XCD b % 8 and
+        // the tile count is a multiple of 8, so blockIdx.x decides the XCD for every split).  That XCD's L2 is then the coherence
+        // point of everything the tile's blocks exchange: slabs travel as PLAIN stores / loads (a store is in L2 once vmcnt has
+        // drained; the last block's loads are first touches of those lines in this launch, and L1 is invalidated between
+        // launches), the counters as workgroup-scope atomics (every atomic executes in L2) -- no write-through, no trip to the
+        // device-coherent memory side, which is what made the agent-scope form below lose to the reduce launch.
+        const bool local = p.g.xcd_local != 0;
+        if (tid == 0)
+            *flag = local ? __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                          : __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int ticket = *flag;
         u64* slab0 = reinterpret_cast<u64*>(d.ws) + (size_t)tile_id * (nsplit - 1) * (size_t)(G2 * NT);
@@ -501,27 +510,40 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
 #pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        __hip_atomic_store(mine + ((i * NI + j) * 8 + g) * NT,
-                                           __builtin_bit_cast(u64, f32x2{acc[i][j][g * 2], acc[i][j][g * 2 + 1]}),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are acknowledged at device scope
+                    for (int g = 0; g < 8; ++g) {
+                        const u64 v = __builtin_bit_cast(u64, f32x2{acc[i][j][g * 2], acc[i][j][g * 2 + 1]});
+                        if (local) mine[((i * NI + j) * 8 + g) * NT] = v;
+                        else __hip_atomic_store(mine + ((i * NI + j) * 8 + g) * NT, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are acknowledged (L2 / device scope)
             __syncthreads();                                   // ... and every wave's
-            if (tid == 0) __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                if (local) __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
         if (tid == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsplit - 1) {
+            for (;;) {
+                const int done = local ? __hip_atomic_fetch_add(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)   // an RMW: never served by L1
+                                       : __hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done >= nsplit - 1) break;
                 __builtin_amdgcn_s_sleep(8);
                 // never seen (ticket holders are resident).  A bounded wait cannot hang the device, and giving up must not
                 // look like success: trap -- the launch fails, the host sees the error, the counters are NOT re-armed
                 if (++spins > (1u << 24)) __builtin_trap();
             }
-            __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-            __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (local) {   // re-arm for the next launch
+                __hip_atomic_exchange(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_exchange(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
+        asm volatile("" ::: "memory");
         const u64* src = slab0 + tid;
         for (int s = 0; s < nsplit - 1; ++s, src += G2 * NT) {
 #pragma unroll
@@ -531,7 +553,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                     u64 v[8];
 #pragma unroll
                     for (int g = 0; g < 8; ++g)
-                        v[g] = __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[g] = local ? *const_cast<const volatile u64*>(src + ((i * NI + j) * 8 + g) * NT)
+                                     : __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         const f32x2 f = __builtin_bit_cast(f32x2, v[g]);

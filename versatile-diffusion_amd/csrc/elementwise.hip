@@ -467,6 +467,20 @@ extern "C" int vd_scale_by_row_norm_f16(void* z, const void* ref, const int32_t*
     return vd_check_launch("vd_scale_by_row_norm_f16");
 }
 
+namespace {
+// which XCD a block runs on (HW_REG_XCC_ID, hwreg 20, bits 3:0) -- the ticketed split of conv3x3_halo_kernel exchanges slabs
+// through the XCD's L2 and relies on the dispatcher's round-robin placement (block b of the linearised grid on XCD b % 8)
+__global__ void probe_xcc_kernel(int32_t* out) {
+    if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = (int32_t)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);
+}
+}  // namespace
+
+extern "C" int vd_probe_xcc_ids(int32_t* out, int grid_x, int grid_y, hipStream_t stream) {
+    VD_REQUIRE(out && grid_x > 0 && grid_y > 0, "vd_probe_xcc_ids: bad arguments");
+    hipLaunchKernelGGL(probe_xcc_kernel, dim3(grid_x, grid_y), dim3(256), 0, stream, out);
+    return vd_check_launch("vd_probe_xcc_ids");
+}
+
 extern "C" int vd_probe_lds_tr16(const int32_t* addr_bytes, int16_t* out, hipStream_t stream) {
     VD_REQUIRE(addr_bytes && out, "vd_probe_lds_tr16: null pointer");
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, addr_bytes, out);

@@ -83,7 +83,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
         const float* w0 = d.ws + (size_t)(row0 + rl) * d.N + col;
-        for (int s = 0; s < nsplit; ++s) {
+        int s = 0;
+        for (; s + 2 <= nsplit; s += 2) {   // 8 independent 16-byte loads in flight before the adds (slab order kept)
+            float4 x[2][2], y[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float* w = w0 + (size_t)(s + t) * slab + (size_t)(32 * u) * d.N;
+                    x[t][u] = *reinterpret_cast<const float4*>(w);
+                    y[t][u] = *reinterpret_cast<const float4*>(w + 4);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    v[u][0] += x[t][u].x; v[u][1] += x[t][u].y; v[u][2] += x[t][u].z; v[u][3] += x[t][u].w;
+                    v[u][4] += y[t][u].x; v[u][5] += y[t][u].y; v[u][6] += y[t][u].z; v[u][7] += y[t][u].w;
+                }
+        }
+        for (; s < nsplit; ++s) {
             float4 x[2], y[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -205,11 +224,17 @@ int plan_stat_rows(const GemmArgs& a, int cfg, int nsplit, const ConvHaloArgs* h
     if (d.N % 8 != 0 || d.ldc % 8 != 0 || ((d.flags & VD_EPI_RESIDUAL) && d.ldr % 8 != 0)) return 0;
     const int HW = d.stat_img_rows;
     if (HW <= 0 || d.M % HW != 0) return 0;
-    if (nsplit > 1) return (d.sync == nullptr && HW % 64 == 0) ? 64 : 0;   // splitk_reduce_stats_kernel
     if (cfg >= T_COUNT) {
-        if (halo == nullptr || HW != halo->Hv * halo->Wv) return 0;
-        return halo->ngrp == 1 ? d.M / halo->g.tiles_m : HW;
+        // the halo conv's epilogue runs in the kernel itself when it is not split, or when the split is reduced by the tile's
+        // last block (ticket counters supplied and enough of them: the condition of vd_gemm_f16)
+        const bool in_kernel = nsplit <= 1 || (d.sync != nullptr && halo != nullptr && 2l * halo->g.tiles_m * halo->g.tiles_n <= VD_GEMM_SYNC_INTS);
+        if (in_kernel) {
+            if (halo == nullptr || HW != halo->Hv * halo->Wv) return 0;
+            return halo->ngrp == 1 ? d.M / halo->g.tiles_m : HW;
+        }
+        return (d.sync == nullptr && HW % 64 == 0) ? 64 : 0;
     }
+    if (nsplit > 1) return (d.sync == nullptr && HW % 64 == 0) ? 64 : 0;   // splitk_reduce_stats_kernel
     if (!cfg_emits_stats(cfg)) return 0;
     const int bm = kCfg[cfg].bm;
     return HW % bm == 0 ? bm : (bm % HW == 0 ? HW : 0);
@@ -549,6 +574,12 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     if (cfg >= T_COUNT) {   // halo-resident 3x3 convolution; split-K slabs go through the same reduce kernel
         halo.g.nt_store = a.nt_store;
         if (nsplit <= 1 || 2l * halo.g.tiles_m * halo.g.tiles_n > VD_GEMM_SYNC_INTS) halo.g.d.sync = nullptr;
+        {   // ticketed split: blocks are dispatched round-robin over the 8 XCDs in linear order (x fastest); with a tile count
+            // that is a multiple of 8 every split of a tile (same blockIdx.x) lands on XCD blockIdx.x % 8
+            static const char* loc_env = getenv("VD_HALO_XCD_LOCAL");   // development switch: 0 = device-scope exchange
+            const bool want = !(loc_env && loc_env[0] == '0');
+            halo.g.xcd_local = (want && halo.g.d.sync != nullptr && ((long)halo.g.tiles_m * halo.g.tiles_n) % 8 == 0) ? 1 : 0;
+        }
         rc = vd_conv_halo_launch(&halo, cfg - T_COUNT, nsplit, stream);
         if (rc != VD_OK) return rc;
         if (nsplit > 1 && halo.g.d.sync == nullptr) {   // no ticket counters: slabs + the reduce kernel

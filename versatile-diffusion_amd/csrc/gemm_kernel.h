@@ -50,6 +50,7 @@ struct GemmArgs {
     int nt_store;                          // non-temporal output stores (streaming results that nobody re-reads soon)
     int mfast;                             // XCD tile runs walk m fastest (tiles of one weight column panel share an L2)
     int stat_rows;                         // d.out_stats: rows per statistics partial (0 = none emitted by this launch)
+    int xcd_local;                         // halo conv, ticketed split: the blocks of a tile share an XCD (L2-scope exchange)
 };
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros

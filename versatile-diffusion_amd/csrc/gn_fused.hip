@@ -88,61 +88,96 @@ struct GnTableArgs {
     const f16* gamma; const f16* beta;
     int HW, groups;
     float eps;
-    float* table;                    // [B][2][c0 + c1]
+    float* table;                    // [B][2][c0 + c1] (or NULL)
+    f16* scale16; f16* shift16;      // optional fp16 [B][c0 + c1] copies (operands of vd_gemm_row320_chain_f16)
 };
 
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-// grid (groups, B), 256 threads
-__global__ __launch_bounds__(256) void gn_table_kernel(const GnTableArgs a) {
-    __shared__ float sh[4];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// grid (groups, B), ONE wave per (sample, group): the cg x T partials of the group are folded in a single pass around a pivot
+// (the group's first partial mean: sum n_i (mean_i - p), sum M2_i + n_i (mean_i - p)^2 -- no second pass, no LDS, no barrier;
+// the spread of channel means inside a group is part of the group's variance, so the pivot form does not cancel)
+__global__ __launch_bounds__(64) void gn_table_kernel(const GnTableArgs a) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int C = a.c0 + a.c1, cg = C / a.groups;
     const int Tmax = a.T0 > a.T1 ? a.T0 : a.T1;
     const float n0 = (float)(a.HW / a.T0), n1 = a.T1 > 0 ? (float)(a.HW / a.T1) : 0.f;
-    auto partial = [&](int idx, float& n, float2& p) {   // idx over cg x Tmax; false where the source has fewer partials
-        const int ch = g * cg + idx / Tmax, t = idx % Tmax;
+    const int chp = g * cg;
+    const int items = cg * Tmax;
+    // ONE round trip to memory: every lane requests its partials (and its gamma / beta) before anything is consumed; the pivot
+    // is lane 0's first partial (item 0 = first channel of the group, block 0), broadcast from its register
+    constexpr int KI = 8;   // items per lane held in registers (cg * T <= 512: every shape of the UNet / VAE); deeper lists loop
+    float2 pv[KI];
+    float pn[KI];
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const int idx = lane + k * 64;
+        pn[k] = 0.f;
+        pv[k] = make_float2(0.f, 0.f);
+        if (idx < items) {
+            const int cl = idx / Tmax, t = idx - cl * Tmax;
+            const int ch = chp + cl;
+            if (ch < a.c0) {
+                if (t < a.T0) { pn[k] = n0; pv[k] = a.st0[((size_t)b * a.T0 + t) * a.c0 + ch]; }
+            } else {
+                if (t < a.T1) { pn[k] = n1; pv[k] = a.st1[((size_t)b * a.T1 + t) * a.c1 + (ch - a.c0)]; }
+            }
+        }
+    }
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};   // cg <= 128 channels per group
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (lane + k * 64 < cg) {
+            gam[k] = (float)a.gamma[chp + lane + k * 64];
+            bet[k] = (float)a.beta[chp + lane + k * 64];
+        }
+    const float pivot = __shfl(pv[0].x, 0, 64);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const float dm = pv[k].x - pivot;
+        s1 += pn[k] * dm;
+        s2 += pn[k] > 0.f ? pv[k].y + pn[k] * dm * dm : 0.f;
+    }
+    for (int idx = lane + KI * 64; idx < items; idx += 64) {
+        const int cl = idx / Tmax, t = idx - cl * Tmax;
+        const int ch = chp + cl;
+        float n;
+        float2 p;
         if (ch < a.c0) {
-            if (t >= a.T0) return false;
+            if (t >= a.T0) continue;
             n = n0;
             p = a.st0[((size_t)b * a.T0 + t) * a.c0 + ch];
         } else {
-            if (t >= a.T1) return false;
+            if (t >= a.T1) continue;
             n = n1;
             p = a.st1[((size_t)b * a.T1 + t) * a.c1 + (ch - a.c0)];
         }
-        return true;
-    };
-    float acc = 0.f;
-    for (int idx = tid; idx < cg * Tmax; idx += 256) {
-        float n;
-        float2 p;
-        if (partial(idx, n, p)) acc += n * p.x;
+        const float dm = p.x - pivot;
+        s1 += n * dm;
+        s2 += p.y + n * dm * dm;
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
     const float ntot = (float)a.HW * (float)cg;
-    const float mean = block_sum_256(acc, sh) / ntot;
-    acc = 0.f;
-    for (int idx = tid; idx < cg * Tmax; idx += 256) {
-        float n;
-        float2 p;
-        if (partial(idx, n, p)) {
-            const float dm = p.x - mean;
-            acc += p.y + n * dm * dm;
-        }
-    }
-    const float var = block_sum_256(acc, sh) / ntot;
+    const float dmean = s1 / ntot;
+    const float mean = pivot + dmean;
+    const float var = fmaxf(s2 / ntot - dmean * dmean, 0.f);
     const float rstd = rsqrtf(var + a.eps);
-    for (int i = tid; i < cg; i += 256) {
-        const int ch = g * cg + i;
-        const float sc = rstd * (float)a.gamma[ch];
-        a.table[((size_t)b * 2) * C + ch] = sc;
-        a.table[((size_t)b * 2 + 1) * C + ch] = (float)a.beta[ch] - mean * sc;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = lane + k * 64;
+        if (i < cg) {
+            const int ch = chp + i;
+            const float sc = rstd * gam[k];
+            const float sh = bet[k] - mean * sc;
+            if (a.table) {
+                a.table[((size_t)b * 2) * C + ch] = sc;
+                a.table[((size_t)b * 2 + 1) * C + ch] = sh;
+            }
+            if (a.scale16) {
+                a.scale16[(size_t)b * C + ch] = (f16)sc;
+                a.shift16[(size_t)b * C + ch] = (f16)sh;
+            }
+        }
     }
 }
 
@@ -372,19 +407,36 @@ extern "C" int vd_chan_stats_f16(const void* x, long M, int C, int ldx, int rows
     return vd_check_launch("vd_chan_stats_f16");
 }
 
+static int gn_table_launch(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW, const void* gamma,
+                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, hipStream_t stream);
+
 extern "C" int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
                                const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream) {
-    VD_REQUIRE(stats0 && gamma && beta && table, "vd_gn_table_f32: null pointer");
+    VD_REQUIRE(table, "vd_gn_table_f32: null pointer");
+    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, table, nullptr, nullptr, stream);
+}
+
+extern "C" int vd_gn_affine_from_stats_f16(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
+                                           const void* gamma, const void* beta, int groups, float eps, void* scale, void* shift,
+                                           hipStream_t stream) {
+    VD_REQUIRE(scale && shift, "vd_gn_affine_from_stats_f16: null pointer");
+    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, nullptr, scale, shift, stream);
+}
+
+static int gn_table_launch(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW, const void* gamma,
+                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, hipStream_t stream) {
+    VD_REQUIRE(stats0 && gamma && beta, "vd_gn_table_f32: null pointer");
     if (!stats1) { T1 = 0; c1 = 0; }
     VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && groups > 0 && c0 > 0 && c1 >= 0, "vd_gn_table_f32: bad sizes");
-    VD_REQUIRE((c0 + c1) % groups == 0 && (c0 + c1) % 4 == 0, "vd_gn_table_f32: C=%d must divide into %d groups", c0 + c1, groups);
+    VD_REQUIRE((c0 + c1) % groups == 0 && (c0 + c1) % 4 == 0 && (c0 + c1) / groups <= 128, "vd_gn_table_f32: C=%d must divide into %d groups of at most 128 channels", c0 + c1, groups);
     VD_REQUIRE(T0 > 0 && HW % T0 == 0 && (c1 == 0 || (T1 > 0 && HW % T1 == 0)), "vd_gn_table_f32: partials must tile the %d rows of a sample (T0=%d T1=%d)", HW, T0, T1);
     GnTableArgs a;
     a.st0 = reinterpret_cast<const float2*>(stats0); a.T0 = T0; a.c0 = c0;
     a.st1 = reinterpret_cast<const float2*>(stats1); a.T1 = T1; a.c1 = c1;
     a.gamma = reinterpret_cast<const f16*>(gamma); a.beta = reinterpret_cast<const f16*>(beta);
     a.HW = HW; a.groups = groups; a.eps = eps; a.table = table;
-    hipLaunchKernelGGL(gn_table_kernel, dim3(groups, B), dim3(256), 0, stream, a);
+    a.scale16 = reinterpret_cast<f16*>(scale16); a.shift16 = reinterpret_cast<f16*>(shift16);
+    hipLaunchKernelGGL(gn_table_kernel, dim3(groups, B), dim3(64), 0, stream, a);
     return vd_check_launch("vd_gn_table_f32");
 }
 

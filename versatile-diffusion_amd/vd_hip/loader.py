@@ -59,6 +59,7 @@ PROTOTYPES = {
     "vd_groupnorm_from_stats_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_chan_stats_f16": (_I, [_P, ctypes.c_long, _I, _I, _I, _P, _P]),
     "vd_gn_table_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P]),
+    "vd_gn_affine_from_stats_f16": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "vd_gn_apply_table_f16": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "vd_abi_version": (_I, []),
     "vd_probe_mfma_layout": (_I, [_P, _P, _P, _P]),
     "vd_probe_lds_tr16": (_I, [_P, _P, _P]),
+    "vd_probe_xcc_ids": (_I, [_P, _I, _I, _P]),
     "vd_image_to_u8": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "vd_adjust_rank_f16": (_I, [_P, _P, _I, _I, _I, _I, _P, _F, _I, _P, _P]),
     "vd_adjust_rank_workspace_bytes": (_Z, [_I, _I, _I, _I]),

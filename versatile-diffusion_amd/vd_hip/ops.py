@@ -108,7 +108,7 @@ SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
 FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
 # opt-in (VD_HALO_FIXUP=1): the halo conv reduces its channel-chunk split in-kernel through ticket counters instead of the
 # reduce launch.  Correct, not faster: equal at a 2-way split, 9 us slower per conv at 4-way, forward 11.98 vs 11.93 ms.
-HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"
+HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"   # round 4: with the XCD-local exchange (VD_HALO_XCD_LOCAL, default on)
 
 
 def sync_counters(device):
@@ -377,6 +377,12 @@ def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5):
     HW = x.numel() // (B * C)
     sc = torch.empty((B, C), dtype=torch.float16, device=x.device)
     sh = torch.empty((B, C), dtype=torch.float16, device=x.device)
+    st = stats_of(x) if GN_STATS else None
+    if st is not None and C % groups == 0:   # statistics from the producer: no pass over x
+        with _Timed("gn_table_kernel", 0.0, 0.0):
+            _check(lib().vd_gn_affine_from_stats_f16(_ptr(st.buf), st.T, st.C, None, 0, 0, B, HW, _ptr(gamma), _ptr(beta), groups,
+                                                     float(eps), _ptr(sc), _ptr(sh), _stream()))
+        return sc, sh
     ws = workspace(lib().vd_groupnorm_workspace_bytes(B, HW, C, groups), x.device, "gn")
     with _Timed("groupnorm statistics -> affine", 0.0, 2.0 * B * HW * C):
         _check(lib().vd_groupnorm_affine_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(sc), _ptr(sh), _ptr(ws), B, HW, C, groups,
@@ -872,6 +878,13 @@ def probe_lds_tr16(addr_bytes):
     _req(addr_bytes, "addr_bytes", torch.int32)
     out = torch.zeros((64, 4), dtype=torch.int16, device=addr_bytes.device)
     _check(lib().vd_probe_lds_tr16(_ptr(addr_bytes), _ptr(out), _stream()))
+    return out.cpu()
+
+
+def probe_xcc_ids(device, grid_x, grid_y=1):
+    """XCD id of every block of a grid_x x grid_y launch -> int32 [grid_y, grid_x] (host)."""
+    out = torch.full((grid_y, grid_x), -1, dtype=torch.int32, device=device)
+    _check(lib().vd_probe_xcc_ids(_ptr(out), int(grid_x), int(grid_y), _stream()))
     return out.cpu()
 
 
