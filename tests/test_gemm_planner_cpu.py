@@ -171,8 +171,9 @@ def test_which_launches_emit_groupnorm_statistics():
     assert stat_rows(8192, 640, 5760, ks=3) == 64
     assert stat_rows(2048, 1280, 11520, ks=3) == 64
     assert stat_rows(512, 1280, 11520, ks=3) == 64
-    # ... but not through the in-kernel fix-up (ticket counters supplied)
-    assert stat_rows(2048, 1280, 11520, ks=3, sync=True) == 0
+    # ... or, with ticket counters, the halo conv's own epilogue (run by the last block of a tile): one partial per patch
+    assert stat_rows(2048, 1280, 11520, ks=3, sync=True) == 256
+    assert stat_rows(512, 1280, 11520, ks=3, sync=True) == 0      # gemm_f16_kernel's last-arriver fix-up emits none
     # SpatialTransformer.proj_out: 1x1 conv on gemm_f16_kernel, one partial per tile (128 rows), or per image where a
     # tile spans several 8x8 images
     assert stat_rows(32768, 320, 320, conv1x1=True) == 128

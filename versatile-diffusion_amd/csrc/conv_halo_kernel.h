@@ -482,6 +482,14 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     // Coherence (XCD L2s are not coherent): slab stores and loads are agent-scope relaxed atomics (sc1: write-through /
     // L1 bypass), ordered against the counters by s_waitcnt vmcnt(0) + the workgroup barrier (MI355X guide, R1 form).
     if (gridDim.y > 1 && d.sync != nullptr) {
+        // an atomic add that returns the old value, executed in the XCD's L2 (sc0 = return; no sc1: not device scope).  Inline
+        // asm on purpose: the compiler may turn a workgroup-scope `fetch_add(p, 0)` into a plain load, which the CU's L1 would
+        // then serve for ever
+        auto l2_add = [](int* ptr, int v) {
+            int old;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(ptr), "v"(v) : "memory");
+            return old;
+        };
         typedef unsigned long long u64;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         constexpr int G2 = MI * NI * 8;   // 8-byte groups per thread
@@ -498,8 +506,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         // device-coherent memory side, which is what made the agent-scope form below lose to the reduce launch.
         const bool local = p.g.xcd_local != 0;
         if (tid == 0)
-            *flag = local ? __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                          : __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = local ? l2_add(ticket_ctr, 1) : __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int ticket = *flag;
         u64* slab0 = reinterpret_cast<u64*>(d.ws) + (size_t)tile_id * (nsplit - 1) * (size_t)(G2 * NT);
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are acknowledged (L2 / device scope)
             __syncthreads();                                   // ... and every wave's
             if (tid == 0) {
-                if (local) __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (local) l2_add(done_ctr, 1);
                 else __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
@@ -526,17 +533,17 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         if (tid == 0) {
             unsigned spins = 0;
             for (;;) {
-                const int done = local ? __hip_atomic_fetch_add(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)   // an RMW: never served by L1
+                const int done = local ? l2_add(done_ctr, 0)   // an RMW: never served by L1
                                        : __hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (done >= nsplit - 1) break;
                 __builtin_amdgcn_s_sleep(8);
                 // never seen (ticket holders are resident).  A bounded wait cannot hang the device, and giving up must not
                 // look like success: trap -- the launch fails, the host sees the error, the counters are NOT re-armed
-                if (++spins > (1u << 24)) __builtin_trap();
+                if (++spins > (1u << 18)) __builtin_trap();
             }
             if (local) {   // re-arm for the next launch
-                __hip_atomic_exchange(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_exchange(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                l2_add(ticket_ctr, -nsplit);
+                l2_add(done_ctr, -(nsplit - 1));
             } else {
                 __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                     u64 v[8];
 #pragma unroll
                     for (int g = 0; g < 8; ++g)
-                        v[g] = local ? *const_cast<const volatile u64*>(src + ((i * NI + j) * 8 + g) * NT)
+                        v[g] = local ? src[((i * NI + j) * 8 + g) * NT]
                                      : __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
