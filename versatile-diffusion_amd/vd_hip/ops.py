@@ -362,7 +362,7 @@ def gemm_row320(a0, w, bias=None, res=None, layernorm=False, ln_eps=1e-5, out_sh
 # opt-in (VD_ST_CHAIN=1): GroupNorm (as an affine map) -> proj_in -> LayerNorm -> q|k|v of a 64x64-level SpatialTransformer in one
 # launch + a statistics launch.  Correct (test_row320_chain), measured neutral: 54 + 18 us against 23 + 24 + 39 us for the three
 # launches it replaces, forward 11.18 vs 11.21 ms (tools/gpu_r03_ad.sh).
-ST_CHAIN = os.environ.get("VD_ST_CHAIN", "0") == "1"
+ST_CHAIN = os.environ.get("VD_ST_CHAIN", "1") != "0"   # round 4: on -- with the GroupNorm statistics coming from the producer the chained entry (GroupNorm affine -> proj_in -> LayerNorm -> q|k|v in one launch) saves the apply pass (measured -0.03 .. -0.09 ms per forward)
 
 
 def st_chain_supported(B, HW, C, inner):
