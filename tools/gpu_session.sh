@@ -6,6 +6,7 @@
 #   fwd[:ENV=V,ENV=V]              graph-replayed UNet forward at the bench shape (tools/unet_forward.py 3 graph) under the env
 #   shape[:ENV=V,...]              per-shape table of one instrumented forward (tools/shape_profile.py)
 #   bench[:args]                   python bench.py <args>   (commas separate arguments)
+#   gtrace[:ENV=V,...]             the same of the graph-replayed forward (in-graph kernel durations, gaps between kernels)
 #   ktrace[:ENV=V,...]             rocprofv3 --kernel-trace --stats of 6 eager forwards: per-kernel average durations
 #   trace                          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.csv / breakdown
 #   pmc                            FETCH_SIZE / WRITE_SIZE passes over the forward -> pmc_traffic.json
@@ -30,8 +31,11 @@ for step in "$@"; do
         envrun "$arg" timeout 600 python tools/unet_forward.py 3 graph > $O/$tag.log 2>&1; echo "rc=$?"; tail -3 $O/$tag.log ;;
     shape)
         envrun "$arg" timeout 600 python tools/shape_profile.py > $O/$tag.txt 2>&1; echo "rc=$?"; head -40 $O/$tag.txt ;;
-    bench)
-        timeout 1500 python bench.py $(echo "$arg" | tr ',' ' ') > $O/$tag.json 2> $O/$tag.err; echo "rc=$?"; tail -1 $O/$tag.json | cut -c1-1500 ;;
+    bench)    # bench:args   or   bench:ENV=V,ENV=V;args
+        benv=""; bargs="$arg"
+        case "$arg" in *\;*) benv="${arg%%;*}"; bargs="${arg#*;}" ;; esac
+        envrun "$benv" timeout 1500 python bench.py $(echo "$bargs" | tr ',' ' ') > $O/$tag.json 2> $O/$tag.err; echo "rc=$?"
+        tail -1 $O/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','ms_per_step','unet_forward_ms_per_ddim_step_bs4','whole_path_frac_of_mfma_peak')}, {k: v.get('value') for k, v in (d.get('other_workloads') or {}).items()}, (d.get('roofline') or {}).get('frac'))" ;;
     trace)
         (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/$tag.log 2>&1); echo "rc=$?"
         DB=$(find $O/prof_bench -name "*.db" | head -1)
@@ -39,6 +43,12 @@ for step in "$@"; do
         NF=$(python tools/count_forwards.py $DB); echo "forwards in the traced run: $NF"
         python tools/kernel_breakdown.py $DB $NF > $O/kernel_breakdown.txt 2>&1; head -30 $O/kernel_breakdown.txt
         rm -rf $O/prof_bench ;;
+    gtrace)   # kernel trace of the GRAPH-replayed forward (3 eager + 60 replays: the averages are the in-graph durations)
+        (cd /tmp && export TMPDIR=/tmp && envrun "$arg" timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/tools/unet_forward.py 3 graph > $O/$tag.log 2>&1); echo "rc=$?"; tail -3 $O/$tag.log
+        DB=$(find $O/prof_$n -name "*.db" | head -1)
+        python tools/kernel_stats.py $DB > $O/$tag.csv 2> $O/$tag.err; head -40 $O/$tag.csv | cut -c1-150
+        python tools/graph_gaps.py $DB > $O/$tag.gaps.txt 2>&1; tail -8 $O/$tag.gaps.txt
+        rm -rf $O/prof_$n ;;
     ktrace)   # kernel trace of a few eager forwards (tools/unet_forward.py) under the env: per-kernel average durations
         (cd /tmp && export TMPDIR=/tmp && envrun "$arg" timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/tools/unet_forward.py 6 > $O/$tag.log 2>&1); echo "rc=$?"
         DB=$(find $O/prof_$n -name "*.db" | head -1)

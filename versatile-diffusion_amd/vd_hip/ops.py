@@ -467,7 +467,9 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
         if st0 is not None or st1 is not None:   # a source without producer statistics is measured with one read of it alone
             st0 = st0 if st0 is not None else chan_stats(x)
             st1 = st1 if (st1 is not None or x1 is None) else chan_stats(x1)
-            if GN_FORM == "fused":   # one launch (block-local fold of the partials, slab-shaped panels)
+            # one launch (block-local fold of the partials, slab-shaped panels): for everything (VD_GN_FORM=fused) or for tensors
+            # of at most VD_GN_FUSED_MAX elements (small, L2-resident: the two launches are at their ~4.8 us floor each there)
+            if GN_FORM == "fused" or B * HW * C <= GN_FUSED_MAX:
                 return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
             # default: a tiny launch folds the partials into the per-(sample, channel) affine map, the apply launch streams
             # whole rows (measured: the slab-shaped single launch reads 80-byte pieces and ran no faster than the old pair)
@@ -486,6 +488,7 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
 # VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
 # come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
 GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
+GN_FUSED_MAX = int(os.environ.get("VD_GN_FUSED_MAX", "2700000"))   # the 16x16 and 8x8 levels (measured: -0.07 ms per forward; 5.3 M: neutral)
 GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
 
