@@ -924,8 +924,9 @@ def test_groupnorm_from_stats(ops, dev, B, HW, c0, c1, R0, R1, silu, eps):
     x0._vd_stats = st0
     out3 = ops.groupnorm_silu(x0, gamma, beta, x1=x1, groups=32, eps=eps, silu=silu)
     assert rel_l2(out3, ref) < 2e-3
-    if ops.GN_STATS and not c1 and ops.GN_FORM == "table":
-        assert torch.equal(out3, out2)   # the dispatch took the statistics on the tensor: same kernels, same partials
+    if ops.GN_STATS and not c1:   # the dispatch took the statistics on the tensor: one of the two forms, same partials
+        small = B * HW * C <= ops.GN_FUSED_MAX or ops.GN_FORM == "fused"
+        assert torch.equal(out3, out if small else out2)
     # run-to-run identical (no atomics)
     assert torch.equal(out, ops.groupnorm_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu))
 
