@@ -41,7 +41,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_FP16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md chip-level table
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # tools/pmc_traffic.py; stamped with the digest of the library it was taken with
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
+TRACE_FILE = "r04_trace_dominant.json"   # tools/trace_dominant.py: rocprofv3 kernel-trace average of the dominant kernel, digest-stamped   # tools/pmc_traffic.py; stamped with the digest of the library it was taken with
 HBM_PEAK_GBS = 8000.0
 UNET_GF_PER_SAMPLE = 803.3       # 64x64 latent, text ctx L=77
 VAE_DECODE_GF = 2514.5
@@ -175,8 +176,25 @@ def roofline_leg(net, wl, batch, device):
             traffic_note = "profiles/%s (library digest %s): %s" % (PMC_TRAFFIC_FILE, pt["library_digest"], pt["note"])
     except Exception as e:
         traffic_note = "no PMC traffic file: %s" % e
+    # ONE stated clock for `achieved` / `frac`: HIP events around every launch of an eager forward (this process).  The
+    # rocprofv3 kernel-trace average of the same kernel (bench command traced separately, profiles/) is carried next to it
+    # when it was taken with the library that is loaded; the trace sees the kernel alone, the events include launch skew.
+    gflop_per_launch = d["gflop"] / max(d["launches"], 1)
+    trace = None
+    try:
+        from vd_hip.loader import lib_digest
+        with open(os.path.join(ROOT, "profiles", TRACE_FILE)) as f:
+            tr = json.load(f)
+        if tr.get("library_digest") == lib_digest() and tr.get("kernel") == dom and wl["cfg"] == 1:
+            tf = gflop_per_launch / (tr["avg_us"] * 1e-3)
+            trace = {"avg_launch_us": tr["avg_us"], "achieved": round(tf, 1), "frac": round(tf / MFMA_FP16_PEAK_TFLOPS, 4),
+                     "calls": tr.get("calls"), "source": "profiles/%s (rocprofv3 --kernel-trace of the bench command)" % TRACE_FILE}
+    except Exception:
+        trace = None
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_FP16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_FP16_PEAK_TFLOPS, 4),
+            "clock": "HIP events on the launch stream around each launch of an eager forward, measured live by this run",
+            "kernel_trace": trace, "traffic": traffic,
             "traffic_note": traffic_note, "algorithmic_bytes_per_launch": int(alg_bytes),
             "traffic_ratio": (round(traffic / alg_bytes, 2) if traffic else None),
             "launches_per_forward": d["launches"], "avg_launch_us": round(d["avg_us"], 1),

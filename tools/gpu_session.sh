@@ -42,6 +42,7 @@ for step in "$@"; do
         python tools/kernel_stats.py $DB > $O/kernel_stats.csv 2> $O/kernel_stats.err; head -12 $O/kernel_stats.csv | cut -c1-220
         NF=$(python tools/count_forwards.py $DB); echo "forwards in the traced run: $NF"
         python tools/kernel_breakdown.py $DB $NF > $O/kernel_breakdown.txt 2>&1; head -30 $O/kernel_breakdown.txt
+        python tools/trace_dominant.py $DB > $O/trace_dominant.json 2> $O/trace_dominant.err; cat $O/trace_dominant.json
         rm -rf $O/prof_bench ;;
     gtrace)   # kernel trace of the GRAPH-replayed forward (3 eager + 60 replays: the averages are the in-graph durations)
         (cd /tmp && export TMPDIR=/tmp && envrun "$arg" timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/tools/unet_forward.py 3 graph > $O/$tag.log 2>&1); echo "rc=$?"; tail -3 $O/$tag.log

@@ -21,7 +21,9 @@ def norm(name):
         if m.group(1) == "gemm_f16_kernel":
             args = args[:7]   # BM, BN, WM, WN, threads, stages, K depth (the 8th, the occupancy hint, is not part of bench.py's names)
         return "%s<%s>" % (m.group(1), ",".join(args))
-    m = re.search(r"(gn_partial_kernel|gn_apply_kernel|gn_slab_kernel|layernorm_kernel|splitk_reduce_kernel)", name)
+    m = re.search(r"(gn_partial_kernel|gn_apply_table_kernel|gn_apply_kernel|gn_slab_kernel|gn_from_stats_kernel|gn_table_kernel|"
+                  r"layernorm_kernel|splitk_reduce_stats_kernel|splitk_reduce_kernel|conv3x3_wstream_kernel|rowchain320_kernel|"
+                  r"rowgemm320_kernel|xattn_kernel)", name)
     return m.group(1) if m else None
 
 

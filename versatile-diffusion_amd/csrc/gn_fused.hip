@@ -20,6 +20,7 @@
 // sigma of the mean), so M2 = S2 - S1^2 / n does not cancel when |mean| >> sigma; partials are combined as
 // M2 = sum M2_i + sum n_i (mean_i - mean)^2 in fp32 (torch's Welford / two-pass robustness, see
 // tests/test_kernels_gpu.py::test_gn_fused_large_mean_small_spread).
+#include <stdlib.h>
 #include "vd_common.h"
 #include "../../include/vd_hip.h"
 
@@ -454,7 +455,9 @@ extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int
     a.R = 256 / a.TC;
     a.npos = (C8 + a.TC - 1) / a.TC;
     // ~16K elements per block (the optimum the round-3 apply kernel measured), whole row-lane trips
-    int rpc = 16384 / C;
+    static const char* chunk_env = getenv("VD_GN_CHUNK");   // development switch: elements per block
+    static const int chunk = chunk_env ? atoi(chunk_env) : 8192;   // 8192: measured best with the light prologue (16384: +0.02 ms, 32768: +0.12)
+    int rpc = chunk / C;
     if (rpc < 1) rpc = 1;
     rpc = ((rpc + a.R - 1) / a.R) * a.R;
     if (rpc > HW) rpc = HW;

@@ -108,6 +108,7 @@ SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
 FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
 # opt-in (VD_HALO_FIXUP=1): the halo conv reduces its channel-chunk split in-kernel through ticket counters instead of the
 # reduce launch.  Correct, not faster: equal at a 2-way split, 9 us slower per conv at 4-way, forward 11.98 vs 11.93 ms.
+HALO_FIXUP_MAXSPLIT = int(os.environ.get("VD_HALO_FIXUP_MAXSPLIT", "32"))   # ... only for splits up to this factor
 HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"   # round 4: with the XCD-local exchange (VD_HALO_XCD_LOCAL, default on)
 
 
@@ -275,7 +276,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             # in-kernel reductions (ticket counters of the halo conv, conv_halo_kernel.h; last-arriver fix-up of
             # gemm_f16_kernel) are opt-in: the reduce launch measured faster for both
             halo = plan_cfg.value >= lib().vd_gemm_num_configs()
-            use_sync = HALO_FIXUP if halo else (FIXUP_DEFAULT if fixup is None else fixup)
+            use_sync = (HALO_FIXUP and plan_ns.value <= HALO_FIXUP_MAXSPLIT) if halo else (FIXUP_DEFAULT if fixup is None else fixup)
             d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
     stats = None
