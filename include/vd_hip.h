@@ -152,6 +152,18 @@ int vd_conv3x3_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStre
 int vd_conv3x3_wstream_supported(const VdGemmDesc* desc);
 /* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */
 int vd_conv3x3_wstream_set_variant(int variant, int target_blocks);
+/* The same weights-in-registers main loop for every 3x3 / stride 1 / pad 1 convolution (optional nearest-2x upsample in
+ * front, optional two-source concat) whose output grid tiles into 128-pixel patches (4 x 32 or 8 x 16 pixels of one image)
+ * and whose output width splits into column tiles of 512 / 384 / 320 / 256 / 128 channels (conv_wreg_kernel.h): a block = 4
+ * waves over one patch, each wave 128 pixels x 32 .. 128 channels with its accumulators in AGPRs, weights streamed from the
+ * fragment-ordered copy (`w_stream`, as above) straight into registers, the input halo of a 64-channel chunk staged in LDS
+ * once.  No split: the fused epilogue of `desc` runs in the kernel (out_stats in partials of 128 rows = one patch); split
+ * over chunks (few patches): fp32 slabs + the reduce kernel (partials of 64 rows).  vd_conv3x3_wreg_plan: dry run --
+ * *supported, the split factor (size desc->ws with vd_gemm_workspace_bytes for it; set desc->ws non-NULL to allow a split)
+ * and the rows per out_stats partial (0: none).  Replaces the reference lines of conv3x3_halo_kernel. */
+int vd_conv3x3_wreg_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
+int vd_conv3x3_wreg_plan(const VdGemmDesc* desc, int* supported, int* nsplit, int* stat_rows);
+int vd_conv3x3_wreg_set_blocks(int target_blocks);   /* development hook: grid size the split aims for (256) */
 int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
 int vd_gemm_tune_clear(void);
 

@@ -1057,3 +1057,65 @@ def test_blocks_are_placed_round_robin_over_the_xcds(ops, dev):
         assert torch.equal(ids, ids[0:1].expand(gy, gx)), "splits of a tile run on different XCDs"
         rot = (ids[0] - torch.arange(gx)) % 8
         assert bool((rot == rot[0]).all()), "placement is not round-robin in block order"
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, c0, c1, Co, ups, rowvec, residual
+    (8, 64, 64, 320, 0, 320, 0, True, False),      # 64x64 level, one (3,2) column tile, 256 patches: fused epilogue
+    (2, 64, 64, 64, 64, 320, 0, False, True),      # concat, residual; 64 patches: split over chunks + reduce
+    (4, 32, 32, 128, 0, 640, 0, True, True),       # column tiles (3,3) + (2,2)
+    (2, 16, 16, 128, 0, 640, 1, False, False),     # Upsample conv: 16x16 -> 32x32
+    (4, 16, 16, 256, 0, 1280, 0, False, True),     # 8 x 16 pixel patches, column tiles (4,4) (4,4) (2,2)
+    (8, 16, 16, 64, 0, 512, 0, True, False),       # one (4,4) tile
+    (1, 96, 96, 64, 0, 320, 0, True, False),       # 768x768 geometry
+    (2, 32, 32, 64, 0, 128, 0, False, False),      # (1,1) tile (VAE width)
+    (8, 32, 32, 64, 64, 384, 0, False, True),      # one (3,3) tile, no split
+    (2, 32, 32, 64, 0, 192, 0, False, False),      # width without a column tiling: stays on the halo kernel
+])
+def test_conv3x3_wreg(ops, dev, case, monkeypatch):
+    """vd_conv3x3_wreg_f16 (weights in registers, 128-pixel patches, every wave layout, fused epilogue and split + reduce)
+    against torch's fp32 convolution; per-channel statistics of the stored output against chan_stats of it."""
+    from vd_hip.loader import lib
+    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
+    monkeypatch.setattr(ops, "WREG", True)
+    B, H, W, c0, c1, Co, ups, rv, rs = case
+    x = rnd((B, H, W, c0), dev, 1.0, 500)
+    x1 = rnd((B, H, W, c1), dev, 1.0, 501) if c1 else None
+    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.04, 502)
+    b = rnd((Co,), dev, 0.3, 503)
+    Hv, Wv = H << ups, W << ups
+    ref = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, ups)
+    kw = dict(ksize=3, pad=1, ups=ups, x1=x1)
+    if rv:
+        rowvec = rnd((B, Co), dev, 0.5, 504)
+        kw.update(rowvec=rowvec, rows_per_batch=Hv * Wv)
+        ref = ref + rowvec.float().view(B, 1, 1, Co)
+    if rs:
+        res = rnd((B, Hv, Wv, Co), dev, 1.0, 505)
+        kw.update(res=res)
+        ref = ref + res.float()
+    wp, wsm = pack_conv_weight(wt), pack_conv_weight_stream(wt)
+    try:
+        for target in (256, 64, 2048):   # no split / fewer blocks / deep split
+            assert lib().vd_conv3x3_wreg_set_blocks(target) == 0
+            out = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw)
+            assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, target
+            outs = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
+            assert rel_l2(outs, ref) < 2e-3, target
+            st = ops.stats_of(outs)
+            assert st is not None and st.HW == Hv * Wv and st.C == Co
+            R = Hv * Wv // st.T
+            o3 = outs.view(B, Hv * Wv, Co)
+            if R == 128 and Co != 192:   # the kernel's own epilogue: a partial is a 128-pixel PATCH (4 x 32 or 8 x 16 pixels)
+                tw = 32 if Wv % 32 == 0 else 16
+                th = 128 // tw
+                o = outs.view(B, Hv // th, th, Wv // tw, tw, Co).permute(0, 1, 3, 2, 4, 5).reshape(B * st.T, 128, Co)
+                refst = torch.stack([o.double().mean(1), ((o.double() - o.double().mean(1, keepdim=True)) ** 2).sum(1)], -1).float()
+                _stats_close(st, refst, R)
+            elif R == 64:
+                _stats_close(st, _chan_stats_ref(o3, B, st.T), R)
+            gamma, beta = rnd((Co,), dev, 0.5, 506) + 1.0, rnd((Co,), dev, 0.5, 507)
+            refn = F.silu(F.group_norm(o3.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
+            assert rel_l2(ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True), refn) < 2e-3
+    finally:
+        lib().vd_conv3x3_wreg_set_blocks(256)

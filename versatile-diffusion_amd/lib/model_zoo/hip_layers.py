@@ -97,9 +97,11 @@ class Conv2d(nn.Conv2d, PackCache):
                 out._vd_stats = st
             return out
         assert in_layout == "nhwc" and in_scale == 1.0 and in_shift == 0.0
-        if (ops.WSTREAM and k == 3 and s == 1 and p == 1 and ups == 0 and pad_hi is None and x.shape[1] == 8 and x.shape[2] == 8
-                and x.shape[0] % 2 == 0 and self.out_channels % 256 == 0 and cin % 64 == 0 and x.shape[-1] % 64 == 0):
-            epi = dict(epi, w_stream=self._w_stream())   # 8x8 level: the layer is its weight stream
+        if k == 3 and s == 1 and p == 1 and pad_hi is None and cin % 64 == 0 and x.shape[-1] % 64 == 0 and self.out_channels % 32 == 0:
+            small = (ops.WSTREAM and ups == 0 and x.shape[1] == 8 and x.shape[2] == 8 and x.shape[0] % 2 == 0
+                     and self.out_channels % 256 == 0)   # 8x8 level: the layer is its weight stream
+            if small or (ops.WREG and (x.shape[2] << ups) % 16 == 0):
+                epi = dict(epi, w_stream=self._w_stream())
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=s, pad=p, ups=ups, x1=x1, pad_hi=pad_hi, **epi)
 
 

@@ -42,6 +42,9 @@ PROTOTYPES = {
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),
+    "vd_conv3x3_wreg_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
+    "vd_conv3x3_wreg_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "vd_conv3x3_wreg_set_blocks": (_I, [_I]),
     "vd_gemm_config_name": (ctypes.c_char_p, [_I]),
     "vd_gemm_num_configs": (_I, []),
     "vd_gemm_set_override": (_I, [_I]),

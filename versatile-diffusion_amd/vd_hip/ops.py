@@ -263,6 +263,38 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if stats is not None:
             out._vd_stats = stats
         return out
+    if w_stream is not None and WREG and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
+        # weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h): plan first (split factor -> workspace,
+        # rows per statistics partial), then launch
+        d.stat_img_rows = int(d.Hout) * int(d.Wout)
+        d.ws = 1   # planning only: a split is allowed
+        sup, pns, prow = ctypes.c_int(0), ctypes.c_int(1), ctypes.c_int(0)
+        _check(lib().vd_conv3x3_wreg_plan(ctypes.byref(d), ctypes.byref(sup), ctypes.byref(pns), ctypes.byref(prow)))
+        d.ws = None
+        if sup.value and (M >= WREG_MIN_M):
+            _req(w_stream, "w_stream")
+            if pns.value > 1:
+                d.split_k = pns.value
+                d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+            else:
+                d.split_k = 1
+            stats = None
+            if want_stats and prow.value > 0:
+                hw = int(d.Hout) * int(d.Wout)
+                sbuf = torch.empty((int(M) // prow.value, n_out, 2), dtype=torch.float32, device=a0.device)
+                d.out_stats = sbuf.data_ptr()
+                stats = ChanStats(sbuf, hw // prow.value, n_out, hw)
+            extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
+            nm = "conv3x3_wreg_kernel"
+            if PROFILE_SHAPES:
+                nm += " M=%d N=%d K=%d split=%d" % (M, N, K, pns.value)
+            a_elems = float(conv["B"]) * conv["Hin"] * conv["Win"] * (d.c0 + d.c1)
+            with _Timed(nm, 2.0 * M * N * K, 2.0 * (a_elems + float(N) * K + float(M) * n_out + extra)):
+                _check(lib().vd_conv3x3_wreg_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
+            if stats is not None:
+                out._vd_stats = stats
+            return out
+        d.stat_img_rows = 0
     # split-K (fp32 slabs + reduce) is the library's answer to small-M / deep-K problems: ask its planner first so
     # the workspace is sized for the split factor it will actually use
     name, d.ws = "gemm", None
@@ -310,6 +342,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     return out
 
 
+WREG = os.environ.get("VD_WREG", "0") == "1"   # 3x3 convolutions on the weights-in-registers kernel where its geometry fits
+WREG_MIN_M = int(os.environ.get("VD_WREG_MIN_M", "0"))
 WSTREAM = os.environ.get("VD_WSTREAM", "1") != "0"   # development switch: 0 = the 8x8-level 3x3 convolutions stay on gemm_f16_kernel
 ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
 
