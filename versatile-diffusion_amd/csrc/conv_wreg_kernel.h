@@ -320,22 +320,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wreg_kernel(const WrArgs p) {
     const bool want_rv = (e.flags & VD_EPI_ROWVEC) != 0;
     const bool want_stats = d.out_stats != nullptr && p.g.stat_rows > 0;
     auto out_row = [&](int m) { return (c.img0 * p.Hv + c.y0 + (m >> p.ltw)) * p.Wv + c.x0 + (m & (p.tw - 1)); };
-    for (int sgm = c.tid; sgm < 128 * CH; sgm += 256) {
-        const int r = sgm / CH, cc = (sgm - r * CH) * 8;
-        const int col = c.n0_blk + cc;
-        const int row = out_row(r);
-        U4H8 t, a, b, o;
-        t.u = *reinterpret_cast<const uint4*>(cs + r * cs_ld + cc);
-        a.u = make_uint4(0, 0, 0, 0);
-        b.u = make_uint4(0, 0, 0, 0);
-        if (want_res) a.u = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
-        if (want_rv) b.u = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
+    // the residual / row-vector segments of a batch of 8 segments per thread are requested before any is consumed (the
+    // accumulators are dead by now: registers are free, and a serial load -> add -> store chain per segment is what this loop
+    // cost in its first version: 47 us of fixed time per 64x64-level launch against 25 for the halo kernel)
+    constexpr int EB = 8;
+    const int nseg = 128 * CH;
+    for (int s0 = c.tid; s0 < nseg; s0 += 256 * EB) {
+        uint4 ra[EB], rb[EB];
+        int rows_[EB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q] + (float)b.e[q]);
-        f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
-        if (p.g.nt_store) vd_store16_nt(dst, o.u);
-        else *reinterpret_cast<uint4*>(dst) = o.u;
-        if (want_stats) *reinterpret_cast<uint4*>(cs + r * cs_ld + cc) = o.u;
+        for (int k = 0; k < EB; ++k) {
+            const int sgm = s0 + k * 256;
+            const int sg = sgm < nseg ? sgm : s0;   // the tail re-requests the first segment (discarded)
+            const int r = sg / CH, cc = (sg - r * CH) * 8;
+            const int col = c.n0_blk + cc;
+            const int row = out_row(r);
+            rows_[k] = row;
+            ra[k] = make_uint4(0, 0, 0, 0);
+            rb[k] = make_uint4(0, 0, 0, 0);
+            if (want_res) ra[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
+            if (want_rv) rb[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+            const int sgm = s0 + k * 256;
+            if (sgm < nseg) {
+                const int r = sgm / CH, cc = (sgm - r * CH) * 8;
+                U4H8 t, a, b, o;
+                t.u = *reinterpret_cast<const uint4*>(cs + r * cs_ld + cc);
+                a.u = ra[k];
+                b.u = rb[k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q] + (float)b.e[q]);
+                f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)rows_[k] * e.ldc + c.n0_blk + cc;
+                if (p.g.nt_store) vd_store16_nt(dst, o.u);
+                else *reinterpret_cast<uint4*>(dst) = o.u;
+                if (want_stats) *reinterpret_cast<uint4*>(cs + r * cs_ld + cc) = o.u;
+            }
+        }
     }
     if (want_stats) {   // one partial per patch: (mean, M2) of the 128 stored values of every channel of the tile
         __syncthreads();
