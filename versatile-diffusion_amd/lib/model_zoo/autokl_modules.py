@@ -26,7 +26,7 @@ class Upsample(nn.Module):
         self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
-        return self.conv(x, ups=1)
+        return self.conv(x, ups=1, want_stats=True)   # feeds a ResnetBlock's GroupNorm: statistics from the conv's epilogue
 
 
 class Downsample(nn.Module):
@@ -37,7 +37,7 @@ class Downsample(nn.Module):
         self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
     def forward(self, x):
-        return self.conv(x, pad_hi=1)  # F.pad(x, (0,1,0,1)) then a valid stride-2 conv
+        return self.conv(x, pad_hi=1, want_stats=True)  # F.pad(x, (0,1,0,1)) then a valid stride-2 conv
 
 
 class ResnetBlock(nn.Module):
@@ -56,10 +56,11 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward(self, x, temb=None):
-        h = self.conv1(self.norm1(x, silu=True))
+        # every tensor between the blocks feeds a GroupNorm: its producer emits the per-channel statistics (csrc/gn_fused.hip)
+        h = self.conv1(self.norm1(x, silu=True), want_stats=True)
         h = self.norm2(h, silu=True)
         res = self.nin_shortcut(x) if self.in_channels != self.out_channels else x
-        return self.conv2(h, res=res)
+        return self.conv2(h, res=res, want_stats=True)
 
 
 class AttnBlock(nn.Module, PackCache):
@@ -85,7 +86,7 @@ class AttnBlock(nn.Module, PackCache):
                                                torch.cat([_h(m.bias) for m in (self.q, self.k, self.v)], 0).contiguous()))
             qkv = ops.linear(hn.view(B, N, C), wqkv, bqkv)
             o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1, scale=float(C) ** -0.5)
-            return self.proj_out(o.view(B, H, W, C), res=x)
+            return self.proj_out(o.view(B, H, W, C), res=x, want_stats=True)
         q = self.q(hn).view(B, N, C)
         k = self.k(hn).view(B, N, C)
         wv, bv = self._packed("v", (self.v.weight, self.v.bias),
@@ -97,7 +98,7 @@ class AttnBlock(nn.Module, PackCache):
                      out_f32=True)
         p = ops.softmax_rows(s)
         o = ops.gemm(p, vt, M=N, N=C, K=N, batch=B, strides=(N * N, C * N, N * C, 0))
-        return self.proj_out(o.view(B, H, W, C), res=x)
+        return self.proj_out(o.view(B, H, W, C), res=x, want_stats=True)
 
 
 def make_attn(in_channels, attn_type="vanilla"):
@@ -142,7 +143,7 @@ class Encoder(nn.Module):
 
     def forward(self, x_nchw, in_scale=1.0, in_shift=0.0):
         """x_nchw fp16 image; the affine (x*2-1 in AutoencoderKL.encode) is applied inside the first gather."""
-        h = self.conv_in(x_nchw, in_layout="nchw", in_scale=in_scale, in_shift=in_shift)
+        h = self.conv_in(x_nchw, in_layout="nchw", in_scale=in_scale, in_shift=in_shift, want_stats=True)
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
                 h = self.down[i_level].block[i_block](h)
@@ -192,7 +193,7 @@ class Decoder(nn.Module):
 
     def forward(self, z_nhwc):
         self.last_z_shape = z_nhwc.shape
-        h = self.conv_in(z_nhwc)
+        h = self.conv_in(z_nhwc, want_stats=True)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
