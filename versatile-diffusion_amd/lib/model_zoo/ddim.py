@@ -27,6 +27,7 @@ class DDIMSampler(object):
         self.schedule = schedule
         self.use_graph = os.environ.get("VD_DDIM_GRAPH", "1") != "0"
         self.graph_cache = os.environ.get("VD_DDIM_GRAPH_CACHE", "1") != "0"   # keep captured steps across sample() calls
+        self.replay_first = os.environ.get("VD_DDIM_REPLAY_FIRST", "1") != "0"   # with a kept graph step 0 is replayed too
         self._static = {}
         # one request at a time per sampler: the kept step graphs read and write static buffers (the reference's sampler is
         # not re-entrant either, but it has no captured state to corrupt; app.py runs Gradio workers unlocked)
@@ -201,14 +202,25 @@ class DDIMSampler(object):
             ts = torch.empty((nb,), device=dev, dtype=torch.long)
             coef = torch.empty((6,), device=dev, dtype=torch.float32)
             graph = None
+            replay_first = False
         else:
             xs, x_next, p0, ts, coef, graph = st["xs"], st["x_next"], st["p0"], st["ts"], st["coef"], st["graph"]
+            replay_first = False
             xs.copy_(x)
             for ci, cbuf, kv in zip(c_info_list, st["c"], st["kv"]):
                 cbuf.copy_(ci["c"])
                 ci["c"] = cbuf
-                kv["_stale"] = set(k for k in kv if k != "_stale")   # K/V of the previous call's context: recomputed in place
+                kv["_stale"] = set(k for k in kv if not (isinstance(k, str) and k.startswith("_")))   # K/V of the previous call's context: recomputed in place
                 ci["kv_cache"] = kv
+            if graph is not None and self.use_graph and self.replay_first and all("_modules" in kv for kv in st["kv"]):
+                # a kept graph: the context K/V projections of this call are refreshed in place right here (16 small GEMMs per
+                # context), so step 0 is replayed like every other step instead of running its ~370 launches eagerly
+                for ci, kv in zip(c_info_list, st["kv"]):
+                    cc = self.model._prep(ci["c"])
+                    for mid in list(kv["_stale"]):
+                        kv[mid].copy_(kv["_modules"][mid][0].project_context(cc))
+                    kv["_stale"].clear()
+                replay_first = True
         table = self._coef_table(total_steps, scale, dev)
         steps_dev = torch.from_numpy(np.ascontiguousarray(time_range).astype(np.int64)).to(dev)
 
@@ -235,7 +247,7 @@ class DDIMSampler(object):
             index = total_steps - i - 1
             ts.copy_(steps_dev[i].expand(nb))       # device-side refresh, no host sync
             coef.copy_(table[index])
-            if i == 0 or not self.use_graph:
+            if (i == 0 and not replay_first) or not self.use_graph:
                 body()
             elif graph is None:
                 graph = self._capture(body)

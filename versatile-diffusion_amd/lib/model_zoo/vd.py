@@ -69,6 +69,7 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
                 if kv is None:
                     kv = module[0].project_context(c)
                     cache[id(module)] = kv
+                    cache.setdefault("_modules", {})[id(module)] = module   # lets the sampler refresh K/V without a forward
                 elif stale and id(module) in stale:   # buffer a captured graph reads: new context, same storage
                     kv.copy_(module[0].project_context(c))
                     stale.discard(id(module))
