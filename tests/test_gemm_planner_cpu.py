@@ -185,3 +185,32 @@ def test_which_launches_emit_groupnorm_statistics():
     assert stat_rows(8192, 5120, 640, act=1) == 0
     assert stat_rows(8192, 640, 640, flags=16) == 0
     assert stat_rows(8192, 1920, 640, flags=32, colsum=True) == 0
+
+
+def test_wreg_column_tiling_covers_the_output_widths():
+    """vd_conv3x3_wreg_plan (dry run): which output widths the weights-in-registers conv tiles into 512 / 384 / 320 / 256 / 128
+    column tiles, split factor and statistics partial for the UNet's 3x3 shapes."""
+    from vd_hip.loader import VdGemmDesc, lib
+
+    def plan(B, H, C, N, ws=True):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = B * H * H, N, 9 * C
+        d.a0 = d.w = d.out = 16
+        d.Hin = d.Win = d.Hout = d.Wout = H
+        d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, C
+        d.stat_img_rows = H * H
+        d.ws = 16 if ws else None
+        sup, ns, rows = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib().vd_conv3x3_wreg_plan(ctypes.byref(d), ctypes.byref(sup), ctypes.byref(ns), ctypes.byref(rows)) == 0
+        return sup.value, ns.value, rows.value
+
+    for N in (128, 256, 320, 384, 448, 512, 576, 640, 768, 1280, 2560):
+        assert plan(8, 64, 64, N)[0] == 1, N
+    for N in (64, 192, 96):          # 64 and 192 have no tiling, 96 is not a multiple of 64
+        assert plan(8, 64, 64, N)[0] == 0, N
+    assert plan(8, 64, 320, 320) == (1, 1, 128)     # 256 patches x one (3,2) tile: no split, one partial per patch
+    assert plan(8, 32, 640, 640) == (1, 2, 64)      # 64 patches x 2 tiles: split 2, statistics from the reduce kernel
+    sup, ns, rows = plan(8, 16, 1280, 1280)
+    assert sup == 1 and 4 <= ns <= 6 and rows == 64  # 16 patches x 3 tiles
+    assert plan(8, 16, 1280, 1280, ws=False)[1] == 1 # no workspace: no split
+    assert plan(8, 24, 64, 320)[0] == 0              # 24 x 24 grid does not tile into 128-pixel patches

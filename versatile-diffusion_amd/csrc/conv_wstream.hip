@@ -123,29 +123,31 @@ const char* wreg_plan(const GemmArgs& a, WrArgs& w) {
     if (tw == 0 || Hv % (128 / tw) != 0) return "an output grid that tiles into 4 x 32 or 8 x 16 pixel patches";
     if ((d.M / npix) * d.Hin * d.Win >= (1l << 28)) return "fewer input pixels";
     if ((d.ldc & 7) || ((d.flags & VD_EPI_RESIDUAL) && (d.ldr & 7))) return "16-byte aligned output rows";
-    // column tiles: widths 512 / 384 / 320 / 256 / 128 = wave layouts (4,4) (3,3) (3,2) (2,2) (1,1), widest first
+    // column tiles: widths 512 / 384 / 320 / 256 / 128 = wave layouts (4,4) (3,3) (3,2) (2,2) (1,1); the fewest tiles that sum
+    // to N exactly (small dynamic program over multiples of 64), widest first
     static const int widths[5] = {512, 384, 320, 256, 128};
     static const int lay0[5] = {4, 3, 3, 2, 1}, lay1[5] = {4, 3, 2, 2, 1};
-    int rem = d.N, n0 = 0, ntn = 0;
-    while (rem > 0) {
-        int pick = -1;
-        for (int k = 0; k < 5 && pick < 0; ++k) {
-            const int r2 = rem - widths[k];
-            if (r2 == 0 || r2 >= 128) {   // the rest must stay decomposable: every multiple of 64 >= 128 except 192 is
-                bool ok = r2 == 0;
-                for (int t = 0; t < 5 && !ok; ++t) ok = r2 == widths[t] || r2 >= 512 + 128 || r2 == 512 + 0;
-                if (!ok)   // small remainders: try sums of two widths
-                    for (int t = 0; t < 5 && !ok; ++t)
-                        for (int u = 0; u < 5 && !ok; ++u) ok = r2 == widths[t] + widths[u];
-                if (ok) pick = k;
+    if (d.N % 64 != 0 || d.N / 64 > 64) return "an output width that is a multiple of 64 (at most 4096)";
+    int best[65], pick[65];   // best[u]: fewest tiles covering u * 64 channels (0 = impossible), pick[u]: the first tile of it
+    best[0] = 0;
+    for (int u = 1; u <= d.N / 64; ++u) {
+        best[u] = 1 << 20;
+        pick[u] = -1;
+        for (int k = 0; k < 5; ++k) {
+            const int wu = widths[k] / 64;
+            if (wu <= u && best[u - wu] + 1 < best[u]) {
+                best[u] = best[u - wu] + 1;
+                pick[u] = k;
             }
         }
-        if (pick < 0 || ntn == WR_MAX_TN) return "an output width that splits into column tiles of 512 / 384 / 320 / 256 / 128";
+    }
+    if (best[d.N / 64] > WR_MAX_TN) return "an output width that splits into column tiles of 512 / 384 / 320 / 256 / 128";
+    int ntn = 0, n0 = 0;
+    for (int u = d.N / 64; u > 0; u -= widths[pick[u]] / 64) {
         w.tn_n0[ntn] = n0;
-        w.tn_ni0[ntn] = lay0[pick];
-        w.tn_ni1[ntn] = lay1[pick];
-        n0 += widths[pick];
-        rem -= widths[pick];
+        w.tn_ni0[ntn] = lay0[pick[u]];
+        w.tn_ni1[ntn] = lay1[pick[u]];
+        n0 += widths[pick[u]];
         ++ntn;
     }
     w.ntn = ntn;
