@@ -347,3 +347,14 @@ def test_draw_initial_latent_device_generator_is_the_reference_draw():
     assert torch.equal(a, torch.randn(shape))
     b = sharded.draw_initial_latent(shape, 7)
     assert torch.equal(b, sharded.draw_initial_latent(shape, 7)) and b.shape == a.shape
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() is what the driver runs on the CPU every round: library built (or re-used when the sources are
+    unchanged), every declared symbol exported, ABI version as the header says, host package importable."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=root, capture_output=True, text=True,
+                       timeout=3000)
+    assert r.returncode == 0 and "build ok" in r.stdout, r.stderr[-2000:]
