@@ -46,6 +46,8 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
 #define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
 #define VD_EPI_LNFOLD 32      /* A rows are LayerNorm'ed on the fly, see VdGemmDesc.colsum     */
 #define VD_EPI_LN_INLOOP 64   /* with VD_EPI_LNFOLD and ln_stats == NULL: row statistics inside the K loop (explicit opt-in) */
+#define VD_EPI_GROUPNORM 128  /* out = [SiLU](GroupNorm(epilogue result)): see VdGemmDesc.gn_gamma; split launches only   */
+#define VD_EPI_GN_SILU 256    /* ... followed by SiLU                                                                      */
 
 #define VD_ACT_NONE 0
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
@@ -102,8 +104,14 @@ typedef struct VdGemmDesc {
                             * [M / R][N][2] = (mean, M2 = sum (x - mean)^2) over blocks of R rows of one image; R =
                             * vd_gemm_stat_rows(desc) (depends on the launch the planner picks; 0 = this launch cannot emit
                             * them: leave out_stats NULL and use vd_chan_stats_f16).  fp16 output, batch 1, N % 8 == 0.     */
-    int32_t stat_img_rows; /* rows of one image for out_stats (partials never mix images); 0 = Hout * Wout (M for plain matrices) */
-    int32_t reserved2;
+    int32_t stat_img_rows; /* rows of one image for out_stats and VD_EPI_GROUPNORM (partials / groups never mix images);
+                            * 0 = Hout * Wout (M for plain matrices)                                                */
+    int32_t gn_groups;     /* VD_EPI_GROUPNORM: number of groups over the N output channels                           */
+    const void* gn_gamma;  /* VD_EPI_GROUPNORM (ABI 5): fp16 [N] scale / shift of a GroupNorm applied to the epilogue result --  */
+    const void* gn_beta;   /* the output is the NORMALISED tensor (the raw one is never stored).  Only launches that are split  */
+    float gn_eps;          /* over K take it: the kernel that sums the fp32 slabs owns whole (sample, channel-slab) panels,    */
+    int32_t reserved3;     /* computes the exact two-pass statistics of its groups in registers and normalises in place.      */
+                           /* Ask vd_gemm_groupnorm_ok(desc) first; res / out_stats are not combined with it.                 */
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -121,6 +129,11 @@ int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
  * read): the halo-resident convolution emits one partial per 256-pixel patch (or per whole small image), gemm_f16_kernel one
  * per min(tile rows, image rows), the split-K reduce one per 64 rows.  *rows = 0: no statistics from this launch. */
 int vd_gemm_stat_rows(const VdGemmDesc* desc, int* rows);
+/* 1 when the launch planned for `desc` (vd_gemm_f16; with conv3x3_wstream != 0: vd_conv3x3_wstream_f16) can take
+ * VD_EPI_GROUPNORM: it is split over K and a (sample, slab of whole groups) panel of the output fits one block's registers.
+ * Replaces conv -> GroupNorm32 -> SiLU of ResBlock.in_layers[2] / out_layers[0:2] (lib/model_zoo/openaimodel.py:196-200,
+ * 230-237,254-274) as: split conv -> ONE kernel that sums the slabs, adds bias + emb, normalises and applies SiLU. */
+int vd_gemm_groupnorm_ok(const VdGemmDesc* desc, int conv3x3_wstream);
 /* "gemm_f16_kernel<BM,BN,WM,WN,NT,STAGES,KB>" of tile_cfg (NULL when out of range); vd_gemm_num_configs() entries. */
 const char* vd_gemm_config_name(int tile_cfg);
 int vd_gemm_num_configs(void);

@@ -1119,3 +1119,48 @@ def test_conv3x3_wreg(ops, dev, case, monkeypatch):
             assert rel_l2(ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True), refn) < 2e-3
     finally:
         lib().vd_conv3x3_wreg_set_blocks(256)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, c0, c1, Co, silu, eps, expect fused
+    (8, 32, 640, 0, 640, True, 1e-5, True),       # 32x32 level: halo conv split 2 -> reduce + GroupNorm in one kernel (960 threads)
+    (8, 16, 1280, 0, 1280, True, 1e-5, True),     # 16x16 level: split 4
+    (8, 16, 1280, 640, 1280, False, 1e-6, True),  # concat input, no SiLU
+    (8, 8, 1280, 0, 1280, True, 1e-5, True),      # 8x8 level: weight-streaming conv
+    (2, 32, 128, 0, 320, True, 1e-5, True),       # 10 channels per group: slabs of 160
+    (8, 64, 320, 0, 320, True, 1e-5, False),      # one block per CU, no split: the conv returns the raw output + statistics
+])
+def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case):
+    """VD_EPI_GROUPNORM: conv (+ bias + per-image row vector) -> GroupNorm -> SiLU where the conv is split over K -- the
+    reduce kernel holds a (sample, slab of groups) panel in registers, two-pass statistics, normalised output only; against
+    torch (conv fp32 -> group_norm -> silu) and against the unfused chain of this library."""
+    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
+    B, H, c0, c1, Co, silu, eps, expect = case
+    x = rnd((B, H, H, c0), dev, 1.0, 600)
+    x1 = rnd((B, H, H, c1), dev, 1.0, 601) if c1 else None
+    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.03, 602)
+    b = rnd((Co,), dev, 0.3, 603)
+    rowvec = rnd((B, Co), dev, 0.5, 604)
+    gamma, beta = rnd((Co,), dev, 0.5, 605) + 1.0, rnd((Co,), dev, 0.5, 606)
+    conv = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, 0) + rowvec.float().view(B, 1, 1, Co)
+    ref = F.group_norm(conv.permute(0, 3, 1, 2), 32, gamma.float(), beta.float(), eps).permute(0, 2, 3, 1)
+    if silu:
+        ref = F.silu(ref)
+    wp = pack_conv_weight(wt)
+    kw = dict(ksize=3, pad=1, x1=x1, rowvec=rowvec, rows_per_batch=H * H)
+    if H == 8:
+        kw["w_stream"] = pack_conv_weight_stream(wt)
+    out = ops.conv2d_nhwc(x, wp, b, want_stats=True, gn=(gamma, beta, 32, eps, silu), **kw)
+    fused = bool(getattr(out, "_vd_normalized", False))
+    assert fused == expect
+    if fused:
+        assert ops.stats_of(out) is None
+        assert rel_l2(out, ref) < 2e-3
+        assert torch.equal(out, ops.conv2d_nhwc(x, wp, b, gn=(gamma, beta, 32, eps, silu), **kw))   # run-to-run identical
+    else:
+        assert rel_l2(out, conv) < 2e-3 and ops.stats_of(out) is not None
+    raw = ops.conv2d_nhwc(x, wp, b, want_stats=True, **kw)
+    chain = ops.groupnorm_silu(raw, gamma, beta, groups=32, eps=eps, silu=silu)
+    assert rel_l2(chain, ref) < 2e-3
+    if fused:
+        assert rel_l2(out, chain) < 2e-3

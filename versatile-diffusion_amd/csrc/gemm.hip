@@ -148,6 +148,180 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
     }
 }
 
+// Split-K reduction fused with the GroupNorm (+ SiLU) that CONSUMES the result (VD_EPI_GROUPNORM): the conv1 -> GroupNorm ->
+// SiLU half of a ResBlock whose conv ran split over K.  A block owns one sample and a slab of whole groups: it sums the
+// nsplit fp32 slabs of its [HW x slab] panel into REGISTERS (+ bias + per-image row vector, activation, alpha), computes the
+// exact two-pass statistics of its groups there (mean, then sum (x - mean)^2: the panel holds every value of the groups),
+// and stores the normalised fp16 panel -- the raw conv output, its statistics buffer, the table launch and the apply launch
+// (reduce 12.5 us + 4.85 + 6-10 us) do not exist.  grid (N / slab, B), NT = blockDim.x threads = slab / 4 column quads x row
+// lanes, RN_ITER rows per thread at most.
+constexpr int RN_ITER = 22;
+struct RnArgs {
+    GemmArgs g;
+    int nsplit, HW, slab, cg;   // rows per sample, channels per block (whole groups, multiple of 4), channels per group
+};
+
+__global__ __launch_bounds__(1024) void splitk_reduce_groupnorm_kernel(const RnArgs p) {
+    extern __shared__ float rn_lds[];   // [RL][slab] partial sums, then [slab] channel sums, [ng] group values
+    const VdGemmDesc& d = p.g.d;
+    const EpiCtx e = make_epi(d, 0);
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int SQ = p.slab / 4, RL = NT / SQ;
+    const int cq = tid % SQ, rl = tid / SQ;
+    const bool active = rl < RL;
+    const int b = blockIdx.y, n0 = blockIdx.x * p.slab;
+    const int col = n0 + cq * 4;
+    const size_t slab_elems = (size_t)d.M * d.N;
+    float4 v[RN_ITER];
+    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        if (e.flags & VD_EPI_BIAS) {
+            U2H4 t;
+            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+            add = make_float4((float)t.e[0], (float)t.e[1], (float)t.e[2], (float)t.e[3]);
+        }
+        if (e.flags & VD_EPI_ROWVEC) {   // rows_per_batch == HW (checked by the planner): one row vector per sample
+            U2H4 t;
+            t.u = *reinterpret_cast<const uint2*>(e.rowvec + (size_t)b * e.N + col);
+            add.x += (float)t.e[0]; add.y += (float)t.e[1]; add.z += (float)t.e[2]; add.w += (float)t.e[3];
+        }
+    }
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < RN_ITER; ++it) {
+        const int r = rl + it * RL;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && r < p.HW) {
+            const float* w0 = d.ws + ((size_t)b * p.HW + r) * d.N + col;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < p.nsplit; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(w0 + (size_t)s * slab_elems);
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            }
+            a.x = apply_act(e.act, a.x + add.x) * e.alpha;
+            a.y = apply_act(e.act, a.y + add.y) * e.alpha;
+            a.z = apply_act(e.act, a.z + add.z) * e.alpha;
+            a.w = apply_act(e.act, a.w + add.w) * e.alpha;
+            v[it] = a;
+            psum.x += a.x; psum.y += a.y; psum.z += a.z; psum.w += a.w;
+        }
+    }
+    // ---- group statistics, two passes over the registers; block reduction: row lanes -> channels -> groups (fixed order)
+    const int ng = p.slab / p.cg;
+    float* red = rn_lds;                       // [RL][slab]
+    float* chs = rn_lds + RL * p.slab;         // [slab]
+    float* grp = chs + p.slab;                 // [2 * ng]: mean, rstd
+    const float ntot = (float)p.HW * (float)p.cg;
+    auto block_groups = [&](const float4& part, int which) {
+        if (active) *reinterpret_cast<float4*>(red + rl * p.slab + cq * 4) = part;
+        __syncthreads();
+        if (tid < p.slab) {
+            float t = 0.f;
+            for (int l = 0; l < RL; ++l) t += red[l * p.slab + tid];
+            chs[tid] = t;
+        }
+        __syncthreads();
+        if (tid < ng) {
+            float t = 0.f;
+            for (int c = 0; c < p.cg; ++c) t += chs[tid * p.cg + c];
+            grp[which * ng + tid] = which == 0 ? t / ntot : rsqrtf(t / ntot + d.gn_eps);
+        }
+        __syncthreads();
+    };
+    block_groups(psum, 0);
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mean[q] = grp[(cq * 4 + q) / p.cg];
+    float4 psq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < RN_ITER; ++it) {
+        const int r = rl + it * RL;
+        if (active && r < p.HW) {
+            const float a = v[it].x - mean[0], bq = v[it].y - mean[1], c2 = v[it].z - mean[2], dq = v[it].w - mean[3];
+            psq.x += a * a; psq.y += bq * bq; psq.z += c2 * c2; psq.w += dq * dq;
+        }
+    }
+    block_groups(psq, 1);
+    if (!active) return;
+    float sc[4], sh[4];
+    {
+        U2H4 gq, bq;
+        gq.u = *reinterpret_cast<const uint2*>(reinterpret_cast<const f16*>(d.gn_gamma) + col);
+        bq.u = *reinterpret_cast<const uint2*>(reinterpret_cast<const f16*>(d.gn_beta) + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rstd[q] = grp[ng + (cq * 4 + q) / p.cg];
+            sc[q] = rstd[q] * (float)gq.e[q];
+            sh[q] = (float)bq.e[q] - mean[q] * sc[q];
+        }
+    }
+    const bool silu = (d.flags & VD_EPI_GN_SILU) != 0;
+    f16* outp = reinterpret_cast<f16*>(e.out);
+#pragma unroll
+    for (int it = 0; it < RN_ITER; ++it) {
+        const int r = rl + it * RL;
+        if (r < p.HW) {
+            const float x4[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+            U2H4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y = fmaf(x4[q], sc[q], sh[q]);
+                o.e[q] = (f16)(silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y)) : y);
+            }
+            *reinterpret_cast<uint2*>(outp + ((size_t)b * p.HW + r) * e.ldc + col) = o.u;
+        }
+    }
+}
+
+// geometry of splitk_reduce_groupnorm_kernel for a (normalised) descriptor; false when it does not fit
+bool groupnorm_reduce_plan(const GemmArgs& a, RnArgs& r, int* threads) {
+    const VdGemmDesc& d = a.d;
+    if (!(d.flags & VD_EPI_GROUPNORM)) return false;
+    if (d.gn_gamma == nullptr || d.gn_beta == nullptr || d.gn_groups <= 0 || d.N % d.gn_groups != 0) return false;
+    if (d.batch != 1 || (d.flags & (VD_EPI_OUT_F32 | VD_EPI_LNFOLD | VD_EPI_BIAS_ALONG_M | VD_EPI_RESIDUAL)) || d.act == VD_ACT_GEGLU) return false;
+    if (d.out_stats != nullptr || d.N % 4 != 0 || d.ldc % 4 != 0) return false;
+    const int HW = d.stat_img_rows;
+    if (HW <= 0 || d.M % HW != 0 || d.M / HW > 65535) return false;
+    if ((d.flags & VD_EPI_ROWVEC) && d.rows_per_batch != HW) return false;
+    const int cg = d.N / d.gn_groups;
+    int unit = cg;   // slab unit: whole groups, whole float4 columns
+    while (unit % 4 != 0) unit += cg;
+    if (d.N % unit != 0) return false;
+    // widest slab (<= 160 channels, dividing N) whose [HW x slab] panel fits 1024 threads x RN_ITER float4
+    int slab = 0;
+    for (int s = unit; s <= 160 && s <= d.N; s += unit)
+        if (d.N % s == 0 && (long)HW * s <= 1024l * 4 * RN_ITER) slab = s;
+    if (slab == 0) return false;
+    const int SQ = slab / 4;
+    int nt = 256;   // the fewest threads (multiples of 64 lanes, whole row-lane sets) that hold the panel
+    for (;; nt += 64) {
+        const int RL = nt / SQ;
+        if (RL > 0 && (long)RL * RN_ITER >= HW) break;
+        if (nt >= 1024) return false;
+    }
+    if ((nt / SQ) * slab * 4 + slab * 4 + 2 * (slab / cg) * 4 > 60 * 1024) return false;
+    r.g = a;
+    r.HW = HW;
+    r.slab = slab;
+    r.cg = cg;
+    *threads = nt;
+    return true;
+}
+
+int launch_reduce_groupnorm(const GemmArgs& a, int nsplit, hipStream_t stream) {
+    RnArgs r;
+    int nt = 0;
+    if (!groupnorm_reduce_plan(a, r, &nt)) {
+        vd_set_error("vd_gemm_f16: VD_EPI_GROUPNORM does not fit this launch (ask vd_gemm_groupnorm_ok first)");
+        return VD_ERR_UNSUPPORTED;
+    }
+    r.nsplit = nsplit;
+    const int RL = nt / (r.slab / 4);
+    const int lds = (RL * r.slab + r.slab + 2 * (r.slab / r.cg)) * 4;
+    hipLaunchKernelGGL(splitk_reduce_groupnorm_kernel, dim3(a.d.N / r.slab, a.d.M / r.HW, 1), dim3(nt), lds, stream, r);
+    return vd_check_launch("vd_gemm_f16/splitk_reduce_groupnorm");
+}
+
 }  // namespace
 
 extern "C" size_t vd_gemm_workspace_bytes(const VdGemmDesc* d) {
@@ -505,6 +679,20 @@ extern "C" int vd_gemm_stat_rows(const VdGemmDesc* dp, int* rows) {
     return VD_OK;
 }
 
+extern "C" int vd_gemm_groupnorm_ok(const VdGemmDesc* dp, int conv3x3_wstream) {
+    if (dp == nullptr) return 0;
+    VdGemmDesc tmp = *dp;
+    tmp.flags |= VD_EPI_GROUPNORM;
+    GemmArgs a;
+    ConvHaloArgs halo;
+    int c = 0, n = 1;
+    if (plan_gemm(&tmp, a, c, n, &halo) != VD_OK) return 0;
+    RnArgs rn;
+    int nt = 0;
+    if (!groupnorm_reduce_plan(a, rn, &nt)) return 0;
+    return (conv3x3_wstream || n > 1) ? 1 : 0;   // the weight-streaming conv always runs split + reduce
+}
+
 extern "C" int vd_gemm_plan(const VdGemmDesc* dp, int* tile_cfg, int* nsplit) {
     GemmArgs a;
     int c = 0, n = 1;
@@ -554,6 +742,14 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         return VD_ERR_UNSUPPORTED;
     }
     VD_REQUIRE(((size_t)d.out_stats & 7) == 0, "vd_gemm_f16: out_stats must be 8-byte aligned");
+    if (d.flags & VD_EPI_GROUPNORM) {
+        RnArgs rn;
+        int nt = 0;
+        a.d.sync = nullptr;
+        halo.g.d.sync = nullptr;
+        VD_REQUIRE(nsplit > 1 && groupnorm_reduce_plan(a, rn, &nt),
+                   "vd_gemm_f16: VD_EPI_GROUPNORM needs a launch that is split over K and a panel that fits (vd_gemm_groupnorm_ok)");
+    }
     const int zb = d.batch;
     static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
@@ -584,6 +780,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         if (rc != VD_OK) return rc;
         if (nsplit > 1 && halo.g.d.sync == nullptr) {   // no ticket counters: slabs + the reduce kernel
             a.d.sync = nullptr;
+            if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
             if (d.out_stats != nullptr) {
                 hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
                 return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
@@ -637,6 +834,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     }
     if (rc != VD_OK) return rc;
     if (nsplit > 1 && a.d.sync == nullptr) {
+        if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
         if (d.out_stats != nullptr) {   // plan_stat_rows: batch 1, fp16 output, whole 64-row blocks per image
             hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
             return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
@@ -662,6 +860,7 @@ int vd_gemm_normalise(const VdGemmDesc* desc, void* gemm_args_out) {
 int vd_gemm_launch_reduce(const void* gemm_args, int nsplit, hipStream_t stream) {
     const GemmArgs& a = *static_cast<const GemmArgs*>(gemm_args);
     const VdGemmDesc& d = a.d;
+    if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
     if (d.out_stats != nullptr) {
         hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
         return vd_check_launch("splitk_reduce_stats");

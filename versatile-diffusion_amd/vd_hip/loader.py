@@ -27,7 +27,8 @@ class VdGemmDesc(ctypes.Structure):
         ("stride_res", ctypes.c_int64),
         ("colsum", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
         ("sync", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p),
-        ("out_stats", ctypes.c_void_p), ("stat_img_rows", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("out_stats", ctypes.c_void_p), ("stat_img_rows", ctypes.c_int32), ("gn_groups", ctypes.c_int32),
+        ("gn_gamma", ctypes.c_void_p), ("gn_beta", ctypes.c_void_p), ("gn_eps", ctypes.c_float), ("reserved3", ctypes.c_int32),
     ]
 
 
@@ -39,6 +40,7 @@ PROTOTYPES = {
     "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_stat_rows": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
+    "vd_gemm_groupnorm_ok": (_I, [ctypes.POINTER(VdGemmDesc), _I]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),

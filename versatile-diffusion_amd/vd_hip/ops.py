@@ -13,6 +13,7 @@ import torch
 from .loader import VdGemmDesc, VdHipError, lib
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD, EPI_LN_INLOOP = 1, 2, 4, 8, 16, 32, 64
+EPI_GROUPNORM, EPI_GN_SILU = 128, 256
 ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 _ws_cache = {}
@@ -165,7 +166,7 @@ def repeat_batch(t, repeat):
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
-         want_stats=False, stat_img_rows=0, w_stream=None):
+         want_stats=False, stat_img_rows=0, w_stream=None, gn=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -179,6 +180,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     launch can emit them, else the attribute is absent.  stat_img_rows: rows of one sample for plain matrices (conv: Hout*Wout).
     w_stream: the same conv weights in MFMA-fragment order (pack.pack_conv_weight_stream); 3x3 convolutions on 8x8 images then
     run on the weight-streaming kernel (vd_conv3x3_wstream_f16) where its geometry fits.
+    gn = (gamma, beta, groups, eps, silu): the GroupNorm (+ SiLU) that consumes this output.  Where the launch is split over K
+    the kernel that sums the slabs normalises in place (VD_EPI_GROUPNORM): the returned tensor is then the NORMALISED one and
+    carries `_vd_normalized = True`; otherwise gn is ignored (the caller runs the norm) and want_stats applies.
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
@@ -245,12 +249,25 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
+    gn_on = False
+    if gn is not None and GN_REDUCE and res is None and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
+        _req(gn[0], "gn gamma"); _req(gn[1], "gn beta")
+        d.gn_gamma, d.gn_beta, d.gn_groups, d.gn_eps = gn[0].data_ptr(), gn[1].data_ptr(), int(gn[2]), float(gn[3])
+        gn_on = True
+        gn_flags = EPI_GROUPNORM | (EPI_GN_SILU if gn[4] else 0)
+        if not stat_img_rows and conv is not None:
+            d.stat_img_rows = int(d.Hout) * int(d.Wout)
+        elif stat_img_rows:
+            d.stat_img_rows = int(stat_img_rows)
     if w_stream is not None and WSTREAM and colsum is None and lib().vd_conv3x3_wstream_supported(ctypes.byref(d)):
         _req(w_stream, "w_stream")
         d.split_k = int(split_k)
         d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
         stats = None
-        if want_stats:
+        fused_gn = gn_on and bool(lib().vd_gemm_groupnorm_ok(ctypes.byref(d), 1))
+        if fused_gn:
+            d.flags = flags | gn_flags
+        if want_stats and not fused_gn:
             sbuf = torch.empty((int(M) // 64, n_out, 2), dtype=torch.float32, device=a0.device)
             d.out_stats = sbuf.data_ptr()
             stats = ChanStats(sbuf, 1, n_out, 64)
@@ -262,6 +279,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             _check(lib().vd_conv3x3_wstream_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
         if stats is not None:
             out._vd_stats = stats
+        if fused_gn:
+            out._vd_normalized = True
         return out
     if w_stream is not None and WREG and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
         # weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h): plan first (split factor -> workspace,
@@ -311,6 +330,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             use_sync = (HALO_FIXUP and plan_ns.value <= HALO_FIXUP_MAXSPLIT) if halo else (FIXUP_DEFAULT if fixup is None else fixup)
             d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+    fused_gn = False
+    if gn_on and plan_ns.value > 1 and d.sync is None and lib().vd_gemm_groupnorm_ok(ctypes.byref(d), 0):
+        fused_gn = True
+        d.flags = flags | gn_flags
+        want_stats = False
     stats = None
     if want_stats and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
         d.stat_img_rows = int(stat_img_rows)
@@ -339,6 +363,8 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
     if stats is not None:
         out._vd_stats = stats
+    if fused_gn:
+        out._vd_normalized = True
     return out
 
 
@@ -523,6 +549,7 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
 # VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
 # come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
 GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
+GN_REDUCE = os.environ.get("VD_GN_REDUCE", "1") != "0"   # conv -> GroupNorm -> SiLU of split launches: normalise inside the reduce kernel
 GN_FUSED_MAX = int(os.environ.get("VD_GN_FUSED_MAX", "2700000"))   # the 16x16 and 8x8 levels (measured: -0.07 ms per forward; 5.3 M: neutral)
 GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
