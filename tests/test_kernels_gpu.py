@@ -1127,14 +1127,15 @@ def test_conv3x3_wreg(ops, dev, case, monkeypatch):
     (8, 16, 1280, 0, 1280, True, 1e-5, True),     # 16x16 level: split 4
     (8, 16, 1280, 640, 1280, False, 1e-6, True),  # concat input, no SiLU
     (8, 8, 1280, 0, 1280, True, 1e-5, True),      # 8x8 level: weight-streaming conv
-    (2, 32, 128, 0, 320, True, 1e-5, True),       # 10 channels per group: slabs of 160
+    (2, 32, 128, 0, 320, True, 1e-5, None),       # 10 channels per group (slab unit 20); split or not is the planner's call
     (8, 64, 320, 0, 320, True, 1e-5, False),      # one block per CU, no split: the conv returns the raw output + statistics
 ])
-def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case):
+def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case, monkeypatch):
     """VD_EPI_GROUPNORM: conv (+ bias + per-image row vector) -> GroupNorm -> SiLU where the conv is split over K -- the
     reduce kernel holds a (sample, slab of groups) panel in registers, two-pass statistics, normalised output only; against
     torch (conv fp32 -> group_norm -> silu) and against the unfused chain of this library."""
     from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
+    monkeypatch.setattr(ops, "GN_REDUCE", True)   # opt-in path
     B, H, c0, c1, Co, silu, eps, expect = case
     x = rnd((B, H, H, c0), dev, 1.0, 600)
     x1 = rnd((B, H, H, c1), dev, 1.0, 601) if c1 else None
@@ -1152,7 +1153,7 @@ def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case):
         kw["w_stream"] = pack_conv_weight_stream(wt)
     out = ops.conv2d_nhwc(x, wp, b, want_stats=True, gn=(gamma, beta, 32, eps, silu), **kw)
     fused = bool(getattr(out, "_vd_normalized", False))
-    assert fused == expect
+    assert expect is None or fused == expect
     if fused:
         assert ops.stats_of(out) is None
         assert rel_l2(out, ref) < 2e-3

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
 // exact two-pass statistics of its groups there (mean, then sum (x - mean)^2: the panel holds every value of the groups),
 // and stores the normalised fp16 panel -- the raw conv output, its statistics buffer, the table launch and the apply launch
 // (reduce 12.5 us + 4.85 + 6-10 us) do not exist.  grid (N / slab, B), NT = blockDim.x threads = slab / 4 column quads x row
-// lanes, RN_ITER rows per thread at most.
-constexpr int RN_ITER = 22;
+// lanes, RN_ITER rows per thread at most (v[] + the loads of one slab in flight fit the 128 registers of a 1024-thread block).
+constexpr int RN_ITER = 12;
 struct RnArgs {
     GemmArgs g;
     int nsplit, HW, slab, cg;   // rows per sample, channels per block (whole groups, multiple of 4), channels per group
@@ -188,16 +188,28 @@ __global__ __launch_bounds__(1024) void splitk_reduce_groupnorm_kernel(const RnA
     }
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
+    for (int it = 0; it < RN_ITER; ++it) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // slab by slab, ALL rows of the thread requested before any is added: RN_ITER independent 16-byte loads in flight (a
+    // per-row loop over the slabs left one load in flight per thread and ran three times slower than the plain reduce)
+    const float* wbase = d.ws + ((size_t)b * p.HW + rl) * d.N + col;
+    const size_t row_step = (size_t)RL * d.N;
+    for (int s = 0; s < p.nsplit; ++s) {
+        float4 x[RN_ITER];
+        const float* ws_ = wbase + (size_t)s * slab_elems;
+#pragma unroll
+        for (int it = 0; it < RN_ITER; ++it) {
+            const bool ok = active && rl + it * RL < p.HW;
+            x[it] = ok ? *reinterpret_cast<const float4*>(ws_ + (size_t)it * row_step) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < RN_ITER; ++it) {
+            v[it].x += x[it].x; v[it].y += x[it].y; v[it].z += x[it].z; v[it].w += x[it].w;
+        }
+    }
+#pragma unroll
     for (int it = 0; it < RN_ITER; ++it) {
-        const int r = rl + it * RL;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && r < p.HW) {
-            const float* w0 = d.ws + ((size_t)b * p.HW + r) * d.N + col;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < p.nsplit; ++s) {
-                const float4 x = *reinterpret_cast<const float4*>(w0 + (size_t)s * slab_elems);
-                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
-            }
+        if (active && rl + it * RL < p.HW) {
+            float4 a = v[it];
             a.x = apply_act(e.act, a.x + add.x) * e.alpha;
             a.y = apply_act(e.act, a.y + add.y) * e.alpha;
             a.z = apply_act(e.act, a.z + add.z) * e.alpha;
@@ -288,8 +300,10 @@ bool groupnorm_reduce_plan(const GemmArgs& a, RnArgs& r, int* threads) {
     while (unit % 4 != 0) unit += cg;
     if (d.N % unit != 0) return false;
     // widest slab (<= 160 channels, dividing N) whose [HW x slab] panel fits 1024 threads x RN_ITER float4
+    static const char* slab_env = getenv("VD_GN_REDUCE_SLAB");   // development switch: widest slab
+    static const int slab_max = slab_env ? atoi(slab_env) : 40;   // narrow slabs = many blocks: 256 at the 16x16 / 8x8 levels
     int slab = 0;
-    for (int s = unit; s <= 160 && s <= d.N; s += unit)
+    for (int s = unit; (s <= slab_max || slab == 0) && s <= 160 && s <= d.N; s += unit)
         if (d.N % s == 0 && (long)HW * s <= 1024l * 4 * RN_ITER) slab = s;
     if (slab == 0) return false;
     const int SQ = slab / 4;

@@ -549,7 +549,10 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
 # VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
 # come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
 GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
-GN_REDUCE = os.environ.get("VD_GN_REDUCE", "1") != "0"   # conv -> GroupNorm -> SiLU of split launches: normalise inside the reduce kernel
+# opt-in (VD_GN_REDUCE=1): conv -> GroupNorm -> SiLU of split launches normalised inside the kernel that sums the slabs
+# (VD_EPI_GROUPNORM).  Correct (test_conv_groupnorm_fused_in_the_reduce) and measured neutral: the panel kernel takes 23.5 us
+# against 13.1 (reduce + statistics) + 9.2 (single-launch norm) -- narrow slabs read partial cache lines (profiles/HISTORY.md)
+GN_REDUCE = os.environ.get("VD_GN_REDUCE", "0") == "1"
 GN_FUSED_MAX = int(os.environ.get("VD_GN_FUSED_MAX", "2700000"))   # the 16x16 and 8x8 levels (measured: -0.07 ms per forward; 5.3 M: neutral)
 GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
