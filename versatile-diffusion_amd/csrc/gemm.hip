@@ -59,66 +59,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     }
 }
 
-// The same reduction for outputs that feed a GroupNorm (VdGemmDesc.out_stats): a block owns 64 rows x 64 columns, sums the
+// The same reduction for outputs that feed a GroupNorm (VdGemmDesc.out_stats): a block owns 64 rows x (8 OCT) columns, sums the
 // slabs, runs the fused epilogue and emits per-channel (mean, M2) of the 64 values it stored per channel (csrc/gn_fused.hip).
-// grid (ceil(N / 64), M / 64), 256 threads = 8 column octets x 32 row lanes (2 rows each)
+// grid (ceil(N / (8 OCT)), M / 64), 256 threads = OCT column octets x 256 / OCT row lanes, RPT = 64 OCT / 256 rows per thread.
+// OCT = 8 (default); OCT = 16 (512-byte row pieces, 16 loads in flight per slab pair) is an opt-in that measured slower.
+template <int OCT>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs p, int nsplit) {
-    __shared__ float red[32][64][2];
-    __shared__ float pivot[64];
+    constexpr int LANES = 256 / OCT, RPT = 64 / LANES, COLS = OCT * 8;
+    __shared__ float red[LANES][COLS][2];
+    __shared__ float pivot[COLS];
     const VdGemmDesc& d = p.d;
     const EpiCtx e = make_epi(d, 0);
-    const int tid = threadIdx.x, co = tid & 7, rl = tid >> 3;
-    const int col = blockIdx.x * 64 + co * 8;
+    const int tid = threadIdx.x, co = tid % OCT, rl = tid / OCT;
+    const int col = blockIdx.x * COLS + co * 8;
     const int row0 = blockIdx.y * 64;
     const size_t slab = (size_t)d.M * d.N;
-    float fin[2][8];
+    float fin[RPT][8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < RPT; ++u)
 #pragma unroll
         for (int i = 0; i < 8; ++i) fin[u][i] = 0.f;
     if (col < d.N) {   // N % 8 == 0: whole octets
-        float v[2][8];
+        float v[RPT][8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < RPT; ++u)
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
         const float* w0 = d.ws + (size_t)(row0 + rl) * d.N + col;
         int s = 0;
-        for (; s + 2 <= nsplit; s += 2) {   // 8 independent 16-byte loads in flight before the adds (slab order kept)
-            float4 x[2][2], y[2][2];
+        for (; s + 2 <= nsplit; s += 2) {   // 4 RPT independent 16-byte loads in flight before the adds (slab order kept)
+            float4 x[2][RPT], y[2][RPT];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float* w = w0 + (size_t)(s + t) * slab + (size_t)(32 * u) * d.N;
+                for (int u = 0; u < RPT; ++u) {
+                    const float* w = w0 + (size_t)(s + t) * slab + (size_t)(LANES * u) * d.N;
                     x[t][u] = *reinterpret_cast<const float4*>(w);
                     y[t][u] = *reinterpret_cast<const float4*>(w + 4);
                 }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RPT; ++u) {
                     v[u][0] += x[t][u].x; v[u][1] += x[t][u].y; v[u][2] += x[t][u].z; v[u][3] += x[t][u].w;
                     v[u][4] += y[t][u].x; v[u][5] += y[t][u].y; v[u][6] += y[t][u].z; v[u][7] += y[t][u].w;
                 }
         }
         for (; s < nsplit; ++s) {
-            float4 x[2], y[2];
+            float4 x[RPT], y[RPT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float* w = w0 + (size_t)s * slab + (size_t)(32 * u) * d.N;
+            for (int u = 0; u < RPT; ++u) {
+                const float* w = w0 + (size_t)s * slab + (size_t)(LANES * u) * d.N;
                 x[u] = *reinterpret_cast<const float4*>(w);
                 y[u] = *reinterpret_cast<const float4*>(w + 4);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RPT; ++u) {
                 v[u][0] += x[u].x; v[u][1] += x[u].y; v[u][2] += x[u].z; v[u][3] += x[u].w;
                 v[u][4] += y[u].x; v[u][5] += y[u].y; v[u][6] += y[u].z; v[u][7] += y[u].w;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            epi_store8(e, row0 + rl + 32 * u, col, v[u]);   // v: the values before the fp16 store
+        for (int u = 0; u < RPT; ++u) {
+            epi_store8(e, row0 + rl + LANES * u, col, v[u]);   // v: the values before the fp16 store
 #pragma unroll
             for (int i = 0; i < 8; ++i) fin[u][i] = (float)(f16)v[u][i];
         }
@@ -131,21 +134,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float k = pivot[co * 8 + i];
-        const float a0 = fin[0][i] - k, a1 = fin[1][i] - k;
-        red[rl][co * 8 + i][0] = a0 + a1;
-        red[rl][co * 8 + i][1] = a0 * a0 + a1 * a1;
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const float a0 = fin[u][i] - k;
+            S += a0;
+            Q += a0 * a0;
+        }
+        red[rl][co * 8 + i][0] = S;
+        red[rl][co * 8 + i][1] = Q;
     }
     __syncthreads();
-    if (tid < 64 && blockIdx.x * 64 + tid < d.N) {
+    if (tid < COLS && blockIdx.x * COLS + tid < d.N) {
         float S = 0.f, Q = 0.f;
 #pragma unroll 8
-        for (int l = 0; l < 32; ++l) {
+        for (int l = 0; l < LANES; ++l) {
             S += red[l][tid][0];
             Q += red[l][tid][1];
         }
-        reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * 64 + tid] =
+        reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * COLS + tid] =
             make_float2(pivot[tid] + S / 64.f, fmaxf(Q - S * S / 64.f, 0.f));
     }
+}
+
+inline void launch_reduce_stats(const GemmArgs& a, int nsplit, hipStream_t stream) {
+    const VdGemmDesc& d = a.d;
+    // 128-column blocks (512-byte row pieces, twice the loads in flight) measured SLOWER than 64-column blocks inside the
+    // forward (10.98 vs 10.89 ms: half as many blocks): development switch VD_REDUCE_WIDE=1 only
+    static const char* w_env = getenv("VD_REDUCE_WIDE");
+    const bool wide = (w_env && w_env[0] == '1') && (long)((d.N + 127) / 128) * (d.M / 64) >= 256;
+    if (wide) hipLaunchKernelGGL(splitk_reduce_stats_kernel<16>, dim3((d.N + 127) / 128, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+    else hipLaunchKernelGGL(splitk_reduce_stats_kernel<8>, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
 }
 
 // Split-K reduction fused with the GroupNorm (+ SiLU) that CONSUMES the result (VD_EPI_GROUPNORM): the conv1 -> GroupNorm ->
@@ -796,7 +815,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
             a.d.sync = nullptr;
             if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
             if (d.out_stats != nullptr) {
-                hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+                launch_reduce_stats(a, nsplit, stream);
                 return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
             }
             const size_t total = (size_t)d.M * ((d.N + 7) / 8);
@@ -850,7 +869,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     if (nsplit > 1 && a.d.sync == nullptr) {
         if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
         if (d.out_stats != nullptr) {   // plan_stat_rows: batch 1, fp16 output, whole 64-row blocks per image
-            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+            launch_reduce_stats(a, nsplit, stream);
             return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
         }
         const size_t total = (size_t)d.M * ((d.N + 7) / 8);
@@ -876,7 +895,7 @@ int vd_gemm_launch_reduce(const void* gemm_args, int nsplit, hipStream_t stream)
     const VdGemmDesc& d = a.d;
     if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
     if (d.out_stats != nullptr) {
-        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+        launch_reduce_stats(a, nsplit, stream);
         return vd_check_launch("splitk_reduce_stats");
     }
     const size_t total = (size_t)d.M * ((d.N + 7) / 8);
