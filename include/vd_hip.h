@@ -112,6 +112,15 @@ typedef struct VdGemmDesc {
     float gn_eps;          /* over K take it: the kernel that sums the fp32 slabs owns whole (sample, channel-slab) panels,    */
     int32_t reserved3;     /* computes the exact two-pass statistics of its groups in registers and normalises in place.      */
                            /* Ask vd_gemm_groupnorm_ok(desc) first; res / out_stats are not combined with it.                 */
+    /* Skip 1x1 convolution folded into a 3x3 convolution (ABI 5): out += W_s [N][skip_c0 + skip_c1] . cat(skip_a0, skip_a1)[pixel]
+     * -- ResBlock's `skip_connection(x) + h` (lib/model_zoo/openaimodel.py:238-251,272-274) as extra K of the second conv
+     * instead of its own GEMM and a residual round trip.  skip_a0 / skip_a1: fp16 tensors on the OUTPUT grid (row strides
+     * skip_lda0 / skip_lda1, channels multiples of 64); skip_w: fp16 [N][skip_ldw], K-contiguous.  Only the halo-resident
+     * convolution takes it (vd_gemm_skip_ok); its bias belongs into `bias`. */
+    const void* skip_a0;
+    const void* skip_a1;
+    const void* skip_w;
+    int32_t skip_c0, skip_c1, skip_lda0, skip_lda1, skip_ldw, reserved4;
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -134,6 +143,9 @@ int vd_gemm_stat_rows(const VdGemmDesc* desc, int* rows);
  * Replaces conv -> GroupNorm32 -> SiLU of ResBlock.in_layers[2] / out_layers[0:2] (lib/model_zoo/openaimodel.py:196-200,
  * 230-237,254-274) as: split conv -> ONE kernel that sums the slabs, adds bias + emb, normalises and applies SiLU. */
 int vd_gemm_groupnorm_ok(const VdGemmDesc* desc, int conv3x3_wstream);
+/* 1 when the launch planned for `desc` takes the folded skip 1x1 convolution (skip_a0 / skip_w set): the halo-resident 3x3
+ * convolution with 256 x 160 blocks, no upsample, the skip tensors on the output grid. */
+int vd_gemm_skip_ok(const VdGemmDesc* desc);
 /* "gemm_f16_kernel<BM,BN,WM,WN,NT,STAGES,KB>" of tile_cfg (NULL when out of range); vd_gemm_num_configs() entries. */
 const char* vd_gemm_config_name(int tile_cfg);
 int vd_gemm_num_configs(void);
@@ -147,7 +159,7 @@ int vd_gemm_set_override(int tile_cfg);
  * tile_cfg = vd_gemm_num_configs() + variant, 0 <= variant < VD_CONV_HALO_VARIANTS (vd_gemm_config_name knows them).
  * Development hook: -1 = planner's choice (default; also the environment variable VD_CONV_HALO), 0 = never (every conv on
  * gemm_f16_kernel), k > 0 = force variant k - 1 where the geometry permits.  Process-global like vd_gemm_set_override. */
-#define VD_CONV_HALO_VARIANTS 12
+#define VD_CONV_HALO_VARIANTS 13
 int vd_conv_halo_set_variant(int setting);
 /* Tuned launch table: a problem (M, N, K, ksize, epilogue class: bit 0 GEGLU, bit 1 LayerNorm fold, bit 2 two-source A) is
  * launched with tile_cfg / split-K nsplit (0 / 1 = none) instead of the cost model's choice.  The host loads the table

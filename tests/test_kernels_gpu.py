@@ -1165,3 +1165,41 @@ def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case, monkeypatch):
     assert rel_l2(chain, ref) < 2e-3
     if fused:
         assert rel_l2(out, chain) < 2e-3
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, C (3x3 input = output width), cs0, cs1
+    (8, 64, 320, 640, 320),      # output block at the 64x64 level: one block per patch, fused epilogue
+    (8, 32, 640, 1280, 640),     # 32x32 level: split 2, skip chunks shared between the splits
+    (8, 16, 1280, 1280, 1280),   # 16x16 level: split 4
+    (8, 32, 640, 320, 0),        # input block 4: single skip source (320 -> 640)
+    (2, 64, 320, 64, 64),        # few patches: deep split, fewer skip chunks than splits
+])
+def test_conv3x3_with_folded_skip_conv(ops, dev, case):
+    """ResBlock's `skip_connection(cat(x, skip)) + conv2(h)` with the 1x1 convolution folded into the halo-resident 3x3
+    convolution as one-tap chunks (VdGemmDesc.skip_*): against torch fp32 (conv3x3 + conv1x1) and the unfused pair."""
+    from vd_hip.pack import pack_conv_weight
+    B, H, C, cs0, cs1 = case
+    h = rnd((B, H, H, C), dev, 1.0, 700)
+    s0 = rnd((B, H, H, cs0), dev, 1.0, 701)
+    s1 = rnd((B, H, H, cs1), dev, 1.0, 702) if cs1 else None
+    w3 = rnd((C, C, 3, 3), dev, 0.03, 703)
+    w1 = rnd((C, cs0 + cs1), dev, 0.03, 704)
+    b = rnd((C,), dev, 0.3, 705)
+    xs = torch.cat([s0, s1], -1) if cs1 else s0
+    ref = _conv_ref(h, w3, b, 1, 1, 0) + (xs.float().reshape(-1, cs0 + cs1) @ w1.float().t()).view(B, H, H, C)
+    wp = pack_conv_weight(w3)
+    out = ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, skip=(s0, s1, w1), want_stats=True)
+    assert out is not None, "the halo kernel should take this launch"
+    assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3
+    st = ops.stats_of(out)
+    assert st is not None
+    if st.T * 64 == H * H:
+        _stats_close(st, _chan_stats_ref(out.view(B, H * H, C), B, st.T), 64)
+    res = ops.gemm(s0.view(-1, cs0), w1, a1=s1.view(-1, cs1) if cs1 else None, K=cs0 + cs1, N=C)
+    pair = ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, res=res.view(B, H, H, C))
+    assert rel_l2(out, pair) < 2e-3
+    assert torch.equal(out, ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, skip=(s0, s1, w1)))
+    # launches the halo kernel does not take return None without running anything
+    assert ops.conv2d_nhwc(h[:, :8, :8].contiguous(), wp, b, ksize=3, pad=1,
+                           skip=(s0[:, :8, :8].contiguous(), None if s1 is None else s1[:, :8, :8].contiguous(), w1)) is None

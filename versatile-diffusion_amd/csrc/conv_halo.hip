@@ -20,6 +20,7 @@ const HaloVariant kHalo[VD_CONV_HALO_VARIANTS] = {
     {256, 128, 512, 3, "conv3x3_halo_kernel<256,128,64,64,512,3>"},
     {128, 32, 256, 4, "conv3x3_halo_kernel<128,32,32,32,256,4>"},
     {128, 160, 256, 2, "conv3x3_halo_kernel<128,160,32,160,256,2>"},
+    {256, 160, 512, 2, "conv3x3_halo_kernel<256,160,32,160,512,2,skip>"},
 };
 
 std::atomic<int> g_halo_variant{-2};   // -2: not read from the environment yet; -1: planner; 0: off; k > 0: force variant k - 1
@@ -176,6 +177,21 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
     if (ns > 1 && !can_split) ns = 1;
     c.chunks_per_split = (c.nchunks + ns - 1) / ns;
     ns = (c.nchunks + c.chunks_per_split - 1) / c.chunks_per_split;
+    c.nskip = 0;
+    c.skip_cps = 0;
+    if (d.skip_a0 != nullptr && d.skip_w != nullptr) {
+        // folded 1x1 skip convolution: the planner's 256 x 160 instance only, inputs on the output grid
+        if (v != 2 || d.ups != 0 || d.skip_c0 % 64 != 0 || d.skip_c1 % 64 != 0 || d.skip_c0 <= 0 || (d.skip_a1 == nullptr && d.skip_c1 != 0)) return 0;
+        const size_t rows = (size_t)d.M;
+        const size_t b0 = rows * (size_t)d.skip_lda0 * 2, b1 = d.skip_a1 ? rows * (size_t)d.skip_lda1 * 2 : 0, bw = (size_t)d.N * d.skip_ldw * 2;
+        if (b0 >= (1ull << 31) || b1 >= (1ull << 31) || bw >= (1ull << 31)) return 0;
+        c.nskip = (d.skip_c0 + d.skip_c1) / 64;
+        c.skip_cps = (c.nskip + ns - 1) / ns;
+        c.s0_bytes = (unsigned)b0;
+        c.s1_bytes = (unsigned)b1;
+        c.sw_bytes = (unsigned)bw;
+        v = 12;
+    }
     *variant_out = v;
     *nsplit_out = ns;
     return 1;
@@ -196,6 +212,7 @@ int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStrea
         case 9: return launch_conv_halo<256, 128, 64, 64, 512, 3>(c, nsplit, stream);
         case 10: return launch_conv_halo<128, 32, 32, 32, 256, 4>(c, nsplit, stream);
         case 11: return launch_conv_halo<128, 160, 32, 160, 256, 2>(c, nsplit, stream);
+        case 12: return launch_conv_halo<256, 160, 32, 160, 512, 2, true>(c, nsplit, stream);
         default: return vd_conv_halo_launch_big(conv_args, variant, nsplit, stream);
     }
 }

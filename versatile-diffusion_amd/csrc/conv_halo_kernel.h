@@ -51,6 +51,8 @@ struct ConvHaloArgs {
     int Hv, Wv;                     // (virtual, i.e. upsampled) image size == output size
     int halo_bytes;                 // one halo buffer: hpx rounded up to whole 8-pixel DMA pieces, x 128
     int abl;                        // -DVD_HALO_ABLATIONS builds only (timing experiments, wrong results): VD_HALO_ABL
+    int nskip, skip_cps;            // SKIP instances: 64-channel chunks of the folded 1x1 skip convolution, per split
+    unsigned s0_bytes, s1_bytes, sw_bytes;   // extents of the skip operands (buffer descriptors)
 };
 #ifdef VD_HALO_ABLATIONS
 #define HALO_ABL(p, k) ((p).abl == (k))
@@ -59,7 +61,9 @@ struct ConvHaloArgs {
 #endif
 
 // MODE 0 / 1 as above.  NT = 64 * waves; wave grid (BM / WM) x (BN / WN), wave tile WM pixels x WN channels.
-template <int BM, int BN, int WM, int WN, int NT, int MODE>
+// SKIP (round 4): behind the 3x3 chunks the block multiplies the chunks of a 1x1 convolution of a second (two-source) input on
+// the same pixels into the same accumulators -- ResBlock's skip_connection(x) + h as extra K of the second conv (d.skip_*).
+template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>
 __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHaloArgs p) {
     constexpr int NW = NT / 64;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -462,6 +466,68 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             });
         }
     }
+    if constexpr (SKIP) {
+        // ---- folded 1x1 skip convolution: its 64-channel chunks are one-tap chunks (the centre pixel of the halo) with their
+        // own weight matrix [N][skip_ldw]; this split takes its share of them.  The main pipeline is drained first, then a
+        // plain two-buffer loop: wait + barrier, request the next chunk's halo and weight tile, four k-steps at the centre tap.
+        // A chunk is 20 MFMAs per wave against 63 KB of DMA: the loop runs at the speed of the loads (~1.2 us per chunk), which
+        // is what the separate GEMM's whole existence (launch, cold start, epilogue, the residual written and re-read) costs more.
+        const int s_begin = split * p.skip_cps;
+        int s_end = s_begin + p.skip_cps;
+        if (s_end > p.nskip) s_end = p.nskip;
+        if (s_begin < s_end) {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();   // main loop drained for every wave: halo buffers and weight stages are free
+            asm volatile("" ::: "memory");
+            const i32x4 ws_s0 = make_rsrc_words(d.skip_a0, p.s0_bytes);
+            const i32x4 ws_s1 = make_rsrc_words(d.skip_a1 ? d.skip_a1 : d.skip_a0, d.skip_a1 ? p.s1_bytes : 0u);
+            const i32x4 ws_sw = make_rsrc_words(d.skip_w, p.sw_bytes);
+            unsigned wv2[WPW];
+#pragma unroll
+            for (int j = 0; j < WPW; ++j) {
+                const int r = (j * NW + wave) * 8 + (lane >> 3);
+                const int n = n0 + r;
+                const int slot = (lane & 7) ^ ((r >> 1) & 7);
+                wv2[j] = (r < BN && n < d.N) ? (unsigned)((n * d.skip_ldw + slot * 8) * 2) : OOB_OFFSET;
+            }
+            auto skip_src = [&](int c) {
+                ChunkSrc s;
+                const int cc = c * 64;
+                const bool second = cc >= d.skip_c0;
+                s.rs = second ? ws_s1 : ws_s0;
+                s.ld2 = (second ? d.skip_lda1 : d.skip_lda0) * 2;
+                s.soff = (unsigned)((second ? cc - d.skip_c0 : cc) * 2);
+                return s;
+            };
+            auto issue_skip = [&](int c, int b) {   // whole halo of skip chunk c -> halo buffer b, its weight tile -> stage b
+                const ChunkSrc cs = skip_src(c);
+                static_for<0, MAXHP>([&](auto jt) { issue_halo(jt, cs, lds0 + (unsigned)(b * p.halo_bytes)); });
+#pragma unroll
+                for (int j = 0; j < WPW; ++j) {
+                    const int q = j * NW + wave_s;
+                    if (q < NPW) dma16(ws_sw, w_lds0 + (unsigned)(b * WSTAGE + q * 1024), wv2[j], (unsigned)(c * 64 * 2));
+                }
+            };
+            issue_skip(s_begin, 0);
+            for (int c = s_begin; c < s_end; ++c) {
+                const int b = (c - s_begin) & 1;
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();   // this chunk has landed for every wave; every wave has left the previous one
+                asm volatile("" ::: "memory");
+                if (c + 1 < s_end) issue_skip(c + 1, b ^ 1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) hrow[i] = hp_base[i];
+                const TapAddr ta = tap_addr(b * p.halo_bytes, p.pitch + 1);   // centre tap (1, 1)
+                const char* wst = w_smem + b * WSTAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    f16x8 af[MI], wf[NI];
+                    read_frags(wst, ta, ks, af, wf);
+                    mma(af, wf);
+                }
+            }
+        }
+    }
     wait_vm<0>();
     __syncthreads();   // every wave is done with halo / weight stages: the epilogue tile re-uses that LDS
 
@@ -696,7 +762,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NT, int MODE>
+template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>
 int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
     constexpr int WST = MODE == 0 ? 2 : 3;
     constexpr int EPI = stat_lds_bytes(BM, BN);   // epilogue tile + the lane scratch of the statistics pass
@@ -711,7 +777,7 @@ int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE, SKIP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             vd_set_error("conv3x3_halo: cannot reserve LDS: %s", hipGetErrorString(e));
@@ -720,7 +786,7 @@ int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
         done.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(a.g.tiles_m * a.g.tiles_n, nsplit, 1);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE>), grid, dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN, NT, MODE, SKIP>), grid, dim3(NT), lds, stream, a);
     return vd_check_launch("conv3x3_halo");
 }
 

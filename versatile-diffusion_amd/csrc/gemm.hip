@@ -474,6 +474,13 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     VD_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "vd_gemm_f16: M=%d is not a multiple of Hout*Wout=%d", d.M, d.Hout * d.Wout);
     if (d.stat_img_rows <= 0) d.stat_img_rows = d.Hout * d.Wout;
     a.stat_rows = 0;
+    if (d.skip_a0 != nullptr || d.skip_w != nullptr) {
+        VD_REQUIRE(d.skip_a0 && d.skip_w && d.ksize == 3, "vd_gemm_f16: the folded skip convolution needs skip_a0, skip_w and a 3x3 convolution");
+        if (d.skip_a1 == nullptr) d.skip_c1 = 0;
+        if (d.skip_lda0 <= 0) d.skip_lda0 = d.skip_c0;
+        if (d.skip_lda1 <= 0) d.skip_lda1 = d.skip_c1;
+        if (d.skip_ldw <= 0) d.skip_ldw = d.skip_c0 + d.skip_c1;
+    }
     const int n_out = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
     if (d.ldc <= 0) d.ldc = n_out;
     if (d.ldr <= 0) d.ldr = n_out;
@@ -569,6 +576,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
             return VD_OK;
         }
     }
+    VD_REQUIRE(d.skip_a0 == nullptr, "vd_gemm_f16: the folded skip convolution is taken by the halo-resident 3x3 convolution only (vd_gemm_skip_ok)");
     TileCfg cfg = T64x64;
     int nsplit = 1;
     if (d.act == VD_ACT_GEGLU) {
@@ -710,6 +718,15 @@ extern "C" int vd_gemm_stat_rows(const VdGemmDesc* dp, int* rows) {
     // plan_stat_rows already answers 0 whenever the caller supplied counters
     if (rows) *rows = a.stat_rows;
     return VD_OK;
+}
+
+extern "C" int vd_gemm_skip_ok(const VdGemmDesc* dp) {
+    if (dp == nullptr || dp->skip_a0 == nullptr || dp->skip_w == nullptr) return 0;
+    GemmArgs a;
+    ConvHaloArgs halo;
+    int c = 0, n = 1;
+    if (plan_gemm(dp, a, c, n, &halo) != VD_OK) return 0;
+    return c == T_COUNT + 12 ? 1 : 0;
 }
 
 extern "C" int vd_gemm_groupnorm_ok(const VdGemmDesc* dp, int conv3x3_wstream) {

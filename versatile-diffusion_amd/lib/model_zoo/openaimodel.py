@@ -170,7 +170,16 @@ class ResBlock(TimestepBlock, PackCache):
             assert skip is None
             res = x
         else:
-            res = self.skip_connection(x, x1=skip)
+            # skip_connection(cat(x, skip)) + conv2(h): the 1x1 convolution rides in the second conv as extra K (one-tap chunks
+            # behind the 3x3 chunks of the halo kernel) where that kernel runs -- no separate GEMM, no residual round trip
+            sc, c2 = self.skip_connection, self.out_layers[3]
+            wsk, _ = sc._w()
+            bsum = self._packed("b2s", (c2.bias, sc.bias),
+                                lambda: (c2.bias.detach().float() + sc.bias.detach().float()).to(torch.float16).contiguous())
+            out = c2(h, bias=bsum, skip=(x, skip, wsk), want_stats=True)
+            if out is not None:
+                return out
+            res = sc(x, x1=skip)
         return self.out_layers[3](h, res=res, want_stats=True)
 
 

@@ -29,6 +29,9 @@ class VdGemmDesc(ctypes.Structure):
         ("sync", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p),
         ("out_stats", ctypes.c_void_p), ("stat_img_rows", ctypes.c_int32), ("gn_groups", ctypes.c_int32),
         ("gn_gamma", ctypes.c_void_p), ("gn_beta", ctypes.c_void_p), ("gn_eps", ctypes.c_float), ("reserved3", ctypes.c_int32),
+        ("skip_a0", ctypes.c_void_p), ("skip_a1", ctypes.c_void_p), ("skip_w", ctypes.c_void_p),
+        ("skip_c0", ctypes.c_int32), ("skip_c1", ctypes.c_int32), ("skip_lda0", ctypes.c_int32), ("skip_lda1", ctypes.c_int32),
+        ("skip_ldw", ctypes.c_int32), ("reserved4", ctypes.c_int32),
     ]
 
 
@@ -41,6 +44,7 @@ PROTOTYPES = {
     "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_stat_rows": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_groupnorm_ok": (_I, [ctypes.POINTER(VdGemmDesc), _I]),
+    "vd_gemm_skip_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),

@@ -166,7 +166,7 @@ def repeat_batch(t, repeat):
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
-         want_stats=False, stat_img_rows=0, w_stream=None, gn=None):
+         want_stats=False, stat_img_rows=0, w_stream=None, gn=None, skip=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -183,6 +183,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     gn = (gamma, beta, groups, eps, silu): the GroupNorm (+ SiLU) that consumes this output.  Where the launch is split over K
     the kernel that sums the slabs normalises in place (VD_EPI_GROUPNORM): the returned tensor is then the NORMALISED one and
     carries `_vd_normalized = True`; otherwise gn is ignored (the caller runs the norm) and want_stats applies.
+    skip = (s0, s1 or None, w_skip [N, C_s0 + C_s1]): a 1x1 convolution of cat(s0, s1) on the output grid folded into this 3x3
+    convolution as extra K (ResBlock's skip_connection(x) + h; its bias belongs into `bias`).  Returns None WITHOUT launching
+    when the planned launch cannot take it (vd_gemm_skip_ok): the caller then runs the 1x1 convolution itself.
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32)
@@ -249,6 +252,16 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
+    if skip is not None:
+        s0, s1, wsk = skip
+        _req(s0, "skip s0"); _req(s1, "skip s1"); _req(wsk, "skip w")
+        if not SKIP_FOLD or res is not None or conv is None or s0.shape[-1] % 64 or (s1 is not None and s1.shape[-1] % 64):
+            return None
+        d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk.data_ptr()
+        d.skip_c0, d.skip_c1 = int(s0.shape[-1]), (int(s1.shape[-1]) if s1 is not None else 0)
+        d.skip_lda0, d.skip_lda1, d.skip_ldw = d.skip_c0, d.skip_c1, int(wsk.shape[-1])
+        if int(wsk.shape[-1]) != d.skip_c0 + d.skip_c1 or not lib().vd_gemm_skip_ok(ctypes.byref(d)):
+            return None
     gn_on = False
     if gn is not None and GN_REDUCE and res is None and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
         _req(gn[0], "gn gamma"); _req(gn[1], "gn beta")
@@ -368,6 +381,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     return out
 
 
+SKIP_FOLD = os.environ.get("VD_SKIP_FOLD", "1") != "0"   # ResBlock skip 1x1 convolution as extra K of the second 3x3 conv
 WREG = os.environ.get("VD_WREG", "0") == "1"   # 3x3 convolutions on the weights-in-registers kernel where its geometry fits
 WREG_MIN_M = int(os.environ.get("VD_WREG_MIN_M", "0"))
 WSTREAM = os.environ.get("VD_WSTREAM", "1") != "0"   # development switch: 0 = the 8x8-level 3x3 convolutions stay on gemm_f16_kernel
