@@ -172,7 +172,9 @@ int vd_conv_halo_set_variant(int setting);
  * (n tile t, chunk c, tap, k-step s) holds W[32 t + (l & 31)][tap][64 c + 16 s + 8 (l >> 5) .. + 8] (vd_hip/pack.py:
  * pack_conv_weight_stream) -- every A operand of an MFMA is one coalesced 1-KiB load straight into registers, the input halo
  * of a chunk is staged in LDS once, K is split over chunks (fp32 slabs + the reduce kernel, which runs desc's epilogue and
- * emits desc->out_stats in partials of 64 rows when asked).  vd_conv3x3_wstream_supported: 1 when desc's geometry fits. */
+ * emits desc->out_stats in partials of 64 rows when asked).  A folded skip convolution (desc->skip_a0 / skip_a1 / skip_c0 /
+ * skip_c1) is taken too: desc->skip_w then holds the 1x1 weights in fragment order, fp16 [N / 32][(skip_c0 + skip_c1) / 64][4]
+ * [64 lanes][8] (pack_linear_weight_stream).  vd_conv3x3_wstream_supported: 1 when desc's geometry fits. */
 int vd_conv3x3_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
 int vd_conv3x3_wstream_supported(const VdGemmDesc* desc);
 /* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */

@@ -35,13 +35,16 @@ def test_capi_exports_every_declared_symbol():
 
 def test_gemm_desc_struct_matches_header():
     from vd_hip.loader import VdGemmDesc
-    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4
+    skip = 3 * 8 + 6 * 4   # folded skip convolution (ABI 5): three pointers, five ints + one reserved
+    assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + skip
     assert VdGemmDesc.stride_a.offset == 8 * 8 + 24 * 4
     assert VdGemmDesc.colsum.offset == 8 * 8 + 24 * 4 + 4 * 8   # LayerNorm-fold fields (ABI 2)
-    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 56   # split-K arrival counters (ABI 2)
-    assert VdGemmDesc.ln_stats.offset == ctypes.sizeof(VdGemmDesc) - 48   # LayerNorm-fold row statistics (ABI 2)
-    assert VdGemmDesc.out_stats.offset == ctypes.sizeof(VdGemmDesc) - 40   # producer-emitted GroupNorm statistics (ABI 5)
-    assert VdGemmDesc.gn_gamma.offset == ctypes.sizeof(VdGemmDesc) - 24    # GroupNorm fused into the split-K reduce (ABI 5)
+    assert VdGemmDesc.sync.offset == ctypes.sizeof(VdGemmDesc) - 56 - skip   # split-K arrival counters (ABI 2)
+    assert VdGemmDesc.ln_stats.offset == ctypes.sizeof(VdGemmDesc) - 48 - skip   # LayerNorm-fold row statistics (ABI 2)
+    assert VdGemmDesc.out_stats.offset == ctypes.sizeof(VdGemmDesc) - 40 - skip   # producer-emitted GroupNorm statistics (ABI 5)
+    assert VdGemmDesc.gn_gamma.offset == ctypes.sizeof(VdGemmDesc) - 24 - skip    # GroupNorm fused into the split-K reduce (ABI 5)
+    assert VdGemmDesc.skip_a0.offset == ctypes.sizeof(VdGemmDesc) - skip
+    assert VdGemmDesc.skip_c0.offset == ctypes.sizeof(VdGemmDesc) - 6 * 4
 
 
 def test_model_cfg_bank_resolves_four_flow():

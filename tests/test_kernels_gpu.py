@@ -1047,6 +1047,43 @@ def test_conv3x3_wstream(ops, dev, case):
     _stats_close(st, _chan_stats_ref(out.view(B, 64, Co), B, 1), 64)
 
 
+@pytest.mark.parametrize("case", [
+    (8, 1280, 1280, 1280),   # output blocks 0 / 1 of the UNet: 2560 -> 1280 skip convolution, 40 one-tap chunks over 10 splits
+    (2, 1280, 1280, 0),      # one image group, single skip source
+    (4, 256, 64, 64),        # fewer skip chunks than splits
+])
+def test_conv3x3_wstream_with_folded_skip_conv(ops, dev, case):
+    """The weight-streaming 8x8 convolution with ResBlock's skip 1x1 convolution folded in (fragment-ordered skip weights,
+    one-tap chunks behind the 3x3 chunks): against torch fp32 and against the unfused pair, at several grid targets."""
+    from vd_hip.loader import lib
+    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream, pack_linear_weight_stream
+    B, C, cs0, cs1 = case
+    h = rnd((B, 8, 8, C), dev, 1.0, 720)
+    s0 = rnd((B, 8, 8, cs0), dev, 1.0, 721)
+    s1 = rnd((B, 8, 8, cs1), dev, 1.0, 722) if cs1 else None
+    w3 = rnd((C, C, 3, 3), dev, 0.03, 723)
+    w1 = rnd((C, cs0 + cs1), dev, 0.03, 724)
+    b = rnd((C,), dev, 0.3, 725)
+    xs = torch.cat([s0, s1], -1) if cs1 else s0
+    ref = _conv_ref(h, w3, b, 1, 1, 0) + (xs.float().reshape(-1, cs0 + cs1) @ w1.float().t()).view(B, 8, 8, C)
+    wp, wsm, w1s = pack_conv_weight(w3), pack_conv_weight_stream(w3), pack_linear_weight_stream(w1)
+    try:
+        for target in (256, 64, 1024):
+            assert lib().vd_conv3x3_wstream_set_variant(0, target) == 0
+            out = ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, w_stream=wsm, skip=(s0, s1, w1, w1s), want_stats=True)
+            assert out is not None and out.shape == ref.shape and rel_l2(out, ref) < 2e-3, target
+    finally:
+        lib().vd_conv3x3_wstream_set_variant(0, 256)
+    st = ops.stats_of(out)
+    assert st is not None and st.T == 1
+    _stats_close(st, _chan_stats_ref(out.view(B, 64, C), B, 1), 64)
+    res = ops.gemm(s0.view(-1, cs0), w1, a1=s1.view(-1, cs1) if cs1 else None, K=cs0 + cs1, N=C)
+    pair = ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, w_stream=wsm, res=res.view(B, 8, 8, C))
+    assert rel_l2(out, pair) < 2e-3
+    # without the fragment-ordered skip weights the launch is refused (the caller runs the 1x1 convolution itself)
+    assert ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, w_stream=wsm, skip=(s0, s1, w1)) is None
+
+
 def test_blocks_are_placed_round_robin_over_the_xcds(ops, dev):
     """Block b of the linearised grid runs on XCD b % 8 (up to a rotation): what the XCD-aware tile orders assume for
     locality, and what the ticketed split of conv3x3_halo_kernel relies on for CORRECTNESS -- with a tile count that is a

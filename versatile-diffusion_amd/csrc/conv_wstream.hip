@@ -53,6 +53,10 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     VdGemmDesc tmp = *dp;
     tmp.w = w_stream;          // the K-contiguous weights are not read on this path
     tmp.out_stats = nullptr;   // (validated below, not by the planner of the other kernels)
+    // folded skip convolution: here skip_w holds the 1x1 weights in FRAGMENT order ([N / 32][chunks][4][64 lanes] x 16 bytes,
+    // pack_linear_weight_stream); the planner of vd_gemm_f16 must not see the request (it only knows the halo kernel's form)
+    const void* skip_a0 = dp->skip_a0; const void* skip_a1 = dp->skip_a1; const void* skip_w = dp->skip_w;
+    tmp.skip_a0 = tmp.skip_a1 = tmp.skip_w = nullptr;
     GemmArgs a;
     const int rc = vd_gemm_normalise(&tmp, &a);
     if (rc != VD_OK) return rc;
@@ -75,6 +79,22 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     w.nchunks = (d.c0 + d.c1) / 64;
     w.tiles_m = w.nimg / 2; w.tiles_n = d.N / 256;
     w.a0_bytes = a.a0_bytes; w.a1_bytes = a.a1_bytes;
+    w.s0 = nullptr; w.s1 = nullptr; w.swp = nullptr;
+    w.sc0 = w.sc1 = w.slda0 = w.slda1 = w.nskip = w.skip_cps = 0;
+    w.s0_bytes = w.s1_bytes = 0;
+    if (skip_a0 != nullptr || skip_w != nullptr) {
+        VD_REQUIRE(skip_a0 && skip_w && dp->skip_c0 > 0 && dp->skip_c0 % 64 == 0 && dp->skip_c1 % 64 == 0 && (skip_a1 || dp->skip_c1 == 0),
+                   "vd_conv3x3_wstream_f16: folded skip convolution needs skip_a0, skip_w (fragment order) and channels in multiples of 64");
+        VD_REQUIRE(((size_t)skip_w & 15) == 0, "vd_conv3x3_wstream_f16: skip_w must be 16-byte aligned");
+        w.s0 = reinterpret_cast<const f16*>(skip_a0); w.s1 = reinterpret_cast<const f16*>(skip_a1);
+        w.swp = reinterpret_cast<const uint4*>(skip_w);
+        w.sc0 = dp->skip_c0; w.sc1 = skip_a1 ? dp->skip_c1 : 0;
+        w.slda0 = dp->skip_lda0 > 0 ? dp->skip_lda0 : w.sc0;
+        w.slda1 = dp->skip_lda1 > 0 ? dp->skip_lda1 : w.sc1;
+        w.nskip = (w.sc0 + w.sc1) / 64;
+        w.s0_bytes = (unsigned)((size_t)d.M * w.slda0 * 2);
+        w.s1_bytes = (unsigned)((size_t)d.M * w.slda1 * 2);
+    }
     // split over chunks until about one block per CU: 20 tiles -> 10 splits of 2 (4) chunks at the bench shape
     const int tiles = w.tiles_m * w.tiles_n;
     int var = g_ws_variant.load(std::memory_order_relaxed), target = g_ws_blocks.load(std::memory_order_relaxed);
@@ -93,6 +113,7 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     w.cps = (w.nchunks + nsplit - 1) / nsplit;
     nsplit = (w.nchunks + w.cps - 1) / w.cps;
     w.nsplit = nsplit;
+    w.skip_cps = (w.nskip + nsplit - 1) / nsplit;
     int lrc;
     switch (var) {
         case 1: lrc = launch_wstream<9, 1>(w, tiles * nsplit, stream); break;

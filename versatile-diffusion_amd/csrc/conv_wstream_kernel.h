@@ -35,6 +35,10 @@ struct WsArgs {
     int nchunks, cps;          // 64-channel chunks of the (concatenated) input: in total / per split
     int tiles_m, tiles_n, nsplit;
     unsigned a0_bytes, a1_bytes;
+    // folded 1x1 skip convolution (ResBlock skip_connection as extra K): one-tap chunks behind the 3x3 chunks
+    const f16* s0; const f16* s1; const uint4* swp;   // sources on the same 8x8 grid; weights [N / 32][chunks][4 k-steps][64 lanes] x 16 B
+    int sc0, sc1, slda0, slda1, nskip, skip_cps;
+    unsigned s0_bytes, s1_bytes;
 };
 
 constexpr int WS_PITCH = 11, WS_GPX = 110, WS_IPB = 2, WS_NPIECE = 28, WS_HB = WS_NPIECE * 1024;
@@ -189,6 +193,57 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+    }
+
+    // ---- folded 1x1 skip convolution: this split's share of its 64-channel chunks, 4 k-steps each at the centre tap.  The
+    // work is tiny (32 MFMAs per chunk and wave): a plain loop -- request the chunk's halo and its 8 weight fragments, wait,
+    // barrier, multiply -- instead of the ring.
+    if (p.nskip > 0) {
+        const int s_begin = split * p.skip_cps;
+        int s_end = s_begin + p.skip_cps;
+        if (s_end > p.nskip) s_end = p.nskip;
+        const i32x4 rs_s0 = make_rsrc_words(p.s0, p.s0_bytes);
+        const i32x4 rs_s1 = make_rsrc_words(p.s1 ? p.s1 : p.s0, p.s1 ? p.s1_bytes : 0u);
+        const uint4* sq0 = p.swp + (size_t)nt0 * p.nskip * (4 * 64) + lane;
+        const uint4* sq1 = p.swp + (size_t)(nt0 + 1) * p.nskip * (4 * 64) + lane;
+        for (int c = s_begin; c < s_end; ++c) {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();   // every wave has left the buffer the DMA below refills (buffer 0 is re-used)
+            asm volatile("" ::: "memory");
+            ChunkSrc cs;
+            {
+                const int cc = c * 64;
+                const bool second = cc >= p.sc0;
+                cs.rs = second ? rs_s1 : rs_s0;
+                cs.ld2 = (second ? p.slda1 : p.slda0) * 2;
+                cs.soff = (unsigned)((second ? cc - p.sc0 : cc) * 2);
+            }
+            ws_static_for<0, 7>([&](auto jt) { issue_halo(jt, cs, lds0); });
+            U4H8 sw[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sw[ks][0].u = sq0[((size_t)c * 4 + ks) * 64];
+                sw[ks][1].u = sq1[((size_t)c * 4 + ks) * 64];
+            }
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();   // the halo has landed for every wave
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    U4H8 v;
+                    v.u = *reinterpret_cast<const uint4*>(smem + hp0b[i] + (tkx[1] ^ (ks << 5)) + (WS_PITCH + 1) * 128);   // tap (1, 1)
+                    b4[i] = v.h;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sw[ks][j].h, b4[i], acc[i][j], 0, 0, 0);
+            }
+        }
     }
 
     // ---- fp32 slab of this split for the reduce kernel, straight from registers (4 consecutive floats per lane and group)

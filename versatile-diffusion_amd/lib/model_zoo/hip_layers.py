@@ -80,6 +80,11 @@ class Conv2d(nn.Conv2d, PackCache):
         """MFMA-fragment-ordered copy of the 3x3 weights for the weight-streaming kernel of the 8x8 level."""
         return self._packed("w_stream", (self.weight,), lambda: pack.pack_conv_weight_stream(_h(self.weight)))
 
+    def _w_stream_1x1(self):
+        """Fragment-ordered copy of a 1x1 conv's weights (folded skip convolution of the weight-streaming kernel)."""
+        return self._packed("w_stream_1x1", (self.weight,),
+                            lambda: pack.pack_linear_weight_stream(_h(self.weight).reshape(self.out_channels, self.in_channels)))
+
     def forward(self, x, x1=None, ups=0, pad_hi=None, in_layout="nhwc", in_scale=1.0, in_shift=0.0, bias=None, **epi):
         w, b = self._w()
         if bias is not None:  # caller-supplied (pre-combined) bias vector

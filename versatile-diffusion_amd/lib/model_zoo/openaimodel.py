@@ -176,7 +176,8 @@ class ResBlock(TimestepBlock, PackCache):
             wsk, _ = sc._w()
             bsum = self._packed("b2s", (c2.bias, sc.bias),
                                 lambda: (c2.bias.detach().float() + sc.bias.detach().float()).to(torch.float16).contiguous())
-            out = c2(h, bias=bsum, skip=(x, skip, wsk), want_stats=True)
+            wsk_stream = sc._w_stream_1x1() if (ops.WSTREAM and H == 8 and W == 8 and sc.in_channels % 64 == 0) else None
+            out = c2(h, bias=bsum, skip=(x, skip, wsk, wsk_stream), want_stats=True)
             if out is not None:
                 return out
             res = sc(x, x1=skip)

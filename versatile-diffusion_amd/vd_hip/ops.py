@@ -252,16 +252,24 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     d.rowvec = rowvec.data_ptr() if rowvec is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
+    skip_stream = False
     if skip is not None:
-        s0, s1, wsk = skip
-        _req(s0, "skip s0"); _req(s1, "skip s1"); _req(wsk, "skip w")
+        s0, s1, wsk = skip[:3]
+        wsk_stream = skip[3] if len(skip) > 3 else None   # the same weights in fragment order (weight-streaming conv)
+        _req(s0, "skip s0"); _req(s1, "skip s1"); _req(wsk, "skip w"); _req(wsk_stream, "skip w (stream)")
         if not SKIP_FOLD or res is not None or conv is None or s0.shape[-1] % 64 or (s1 is not None and s1.shape[-1] % 64):
             return None
-        d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk.data_ptr()
         d.skip_c0, d.skip_c1 = int(s0.shape[-1]), (int(s1.shape[-1]) if s1 is not None else 0)
-        d.skip_lda0, d.skip_lda1, d.skip_ldw = d.skip_c0, d.skip_c1, int(wsk.shape[-1])
-        if int(wsk.shape[-1]) != d.skip_c0 + d.skip_c1 or not lib().vd_gemm_skip_ok(ctypes.byref(d)):
+        if int(wsk.shape[-1]) != d.skip_c0 + d.skip_c1:
             return None
+        if (w_stream is not None and wsk_stream is not None and WSTREAM and colsum is None
+                and lib().vd_conv3x3_wstream_supported(ctypes.byref(d))):
+            skip_stream = True   # 8x8 level: one-tap chunks behind the weight stream (fields set below, on that path)
+        else:
+            d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk.data_ptr()
+            d.skip_lda0, d.skip_lda1, d.skip_ldw = d.skip_c0, d.skip_c1, int(wsk.shape[-1])
+            if not lib().vd_gemm_skip_ok(ctypes.byref(d)):
+                return None
     gn_on = False
     if gn is not None and GN_REDUCE and res is None and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
         _req(gn[0], "gn gamma"); _req(gn[1], "gn beta")
@@ -272,8 +280,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             d.stat_img_rows = int(d.Hout) * int(d.Wout)
         elif stat_img_rows:
             d.stat_img_rows = int(stat_img_rows)
-    if w_stream is not None and WSTREAM and colsum is None and lib().vd_conv3x3_wstream_supported(ctypes.byref(d)):
+    if w_stream is not None and WSTREAM and colsum is None and (skip is None or skip_stream) and lib().vd_conv3x3_wstream_supported(ctypes.byref(d)):
         _req(w_stream, "w_stream")
+        if skip_stream:
+            d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk_stream.data_ptr()
+            d.skip_lda0, d.skip_lda1 = d.skip_c0, d.skip_c1
         d.split_k = int(split_k)
         d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
         stats = None
@@ -295,7 +306,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if fused_gn:
             out._vd_normalized = True
         return out
-    if w_stream is not None and WREG and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
+    if w_stream is not None and WREG and skip is None and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
         # weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h): plan first (split factor -> workspace,
         # rows per statistics partial), then launch
         d.stat_img_rows = int(d.Hout) * int(d.Wout)

@@ -19,6 +19,15 @@ def pack_conv_weight_stream(w):
     return v.reshape(co // 32, ci // 64, 9, 4, 64, 8).contiguous()
 
 
+def pack_linear_weight_stream(w):
+    """1x1 conv / linear weight [Cout, Cin] -> MFMA-fragment order [Cout / 32][Cin / 64][4 k-steps][64 lanes][8] (the folded skip
+    convolution of vd_conv3x3_wstream_f16): lane l of (n tile t, chunk c, k-step s) holds W[32 t + (l & 31)][64 c + 16 s + 8 (l >> 5) .. + 8]."""
+    co, ci = w.shape
+    assert co % 32 == 0 and ci % 64 == 0
+    v = w.reshape(co // 32, 32, ci // 64, 4, 2, 8)      # (t, l31, c, s, hi, e)
+    return v.permute(0, 2, 3, 4, 1, 5).reshape(co // 32, ci // 64, 4, 64, 8).contiguous()
+
+
 def pack_conv_weight_small(w, kpad=None):
     """Same ordering, zero padded along K to a multiple of 64 (matches vd_im2col_small_f16)."""
     p = pack_conv_weight(w)
