@@ -474,6 +474,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     VD_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "vd_gemm_f16: M=%d is not a multiple of Hout*Wout=%d", d.M, d.Hout * d.Wout);
     if (d.stat_img_rows <= 0) d.stat_img_rows = d.Hout * d.Wout;
     a.stat_rows = 0;
+#ifdef VD_TIMELINE
+    a.tl = nullptr;
+#endif
     if (d.skip_a0 != nullptr || d.skip_w != nullptr) {
         VD_REQUIRE(d.skip_a0 && d.skip_w && d.ksize == 3, "vd_gemm_f16: the folded skip convolution needs skip_a0, skip_w and a 3x3 convolution");
         if (d.skip_a1 == nullptr) d.skip_c1 = 0;
@@ -780,12 +783,21 @@ extern "C" int vd_gemm_set_override(int tile_cfg) {
     return VD_OK;
 }
 
+#ifdef VD_TIMELINE
+static unsigned long long* g_timeline = nullptr;
+// development build only: per-block phase stamps of the next gemm_f16_kernel launches go to buf (8 x u64 per block), null = off
+extern "C" void vd_debug_set_timeline(void* buf) { g_timeline = reinterpret_cast<unsigned long long*>(buf); }
+#endif
+
 extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     GemmArgs a;
     ConvHaloArgs halo;
     int cfg = 0, nsplit = 1;
     int rc = plan_gemm(dp, a, cfg, nsplit, &halo);
     if (rc != VD_OK) return rc;
+#ifdef VD_TIMELINE
+    a.tl = g_timeline;
+#endif
     const VdGemmDesc& d = a.d;
     if (d.out_stats != nullptr && a.stat_rows == 0) {
         vd_set_error("vd_gemm_f16: out_stats requested but the planned launch cannot emit statistics (vd_gemm_stat_rows = 0)");

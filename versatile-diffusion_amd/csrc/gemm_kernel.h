@@ -51,7 +51,32 @@ struct GemmArgs {
     int mfast;                             // XCD tile runs walk m fastest (tiles of one weight column panel share an L2)
     int stat_rows;                         // d.out_stats: rows per statistics partial (0 = none emitted by this launch)
     int xcd_local;                         // halo conv, ticketed split: the blocks of a tile share an XCD (L2-scope exchange)
+#ifdef VD_TIMELINE
+    unsigned long long* tl;                // development build (tools/probes/gemm_timeline.py): 8 stamps per block, or null
+#endif
 };
+
+// Development builds with -DVD_TIMELINE (VD_EXTRA_DEFS, VD_BUILD_OUT): wall-clock stamps (s_memrealtime, 100 MHz) at the phase
+// boundaries of a block, kept in scalar registers and stored by thread 0 at the very end -- no memory operation is added
+// inside the hand-counted vmcnt regions.  The product library carries none of it.
+#ifdef VD_TIMELINE
+#define VD_TL_DECL unsigned long long vd_tl_t[6] = {0, 0, 0, 0, 0, 0}
+#define VD_TL(i) vd_tl_t[i] = wall_clock64()
+#define VD_TL_FLUSH(ptr)                                                                                              \
+    do {                                                                                                              \
+        if ((ptr) != nullptr && threadIdx.x == 0) {                                                                   \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+            unsigned long long* o_ = (ptr) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
+            for (int i_ = 0; i_ < 6; ++i_) o_[i_] = vd_tl_t[i_];                                                      \
+            o_[6] = wall_clock64();                                                                                   \
+            o_[7] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);                             \
+        }                                                                                                             \
+    } while (0)
+#else
+#define VD_TL_DECL do {} while (0)
+#define VD_TL(i) do {} while (0)
+#define VD_TL_FLUSH(ptr) do {} while (0)
+#endif
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;  // beyond every descriptor's num_records -> hardware returns zeros
 
@@ -341,6 +366,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     static_assert(LPT * (D > 1 ? D - 1 : 1) < 64, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    VD_TL_DECL;
+    VD_TL(0);   // block start
 
     const VdGemmDesc& d = p.d;
     const int tid = threadIdx.x;
@@ -693,6 +720,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
+#ifdef VD_TIMELINE
+            if (i == 0) VD_TL(1);   // first K tile landed for every wave
+#endif
             if (i + D < nk) {
                 issue_begin(kt0 + i + D, ibuf);
 #pragma unroll
@@ -746,6 +776,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     }   // !MID
     wait_vm<0>();
     __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
+    VD_TL(2);   // main loop done
 
     const EpiCtx e = make_epi(d, z);
 
@@ -976,6 +1007,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();
+    VD_TL(3);   // epilogue tile in LDS
 
     // ---- part 2: coalesced 16-byte row segments: (+ rowvec) (+ residual) -> global
     if (geglu) epi_writeout<PROWS, BN / 16, NT, MAX_CH, CS_LD, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, cs, pre, p.nt_store != 0);
@@ -993,6 +1025,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                                            d.out_stats, (size_t)(m0 / R), d.N, n0);
         }
     }
+    VD_TL(4);   // output stores issued (the flush waits for them: stamp 6 = stores acknowledged)
+    VD_TL_FLUSH(p.tl);
 }
 
 template <int BM, int BN, int NT, int STAGES, int KB>

@@ -42,11 +42,16 @@ struct RGArgs {
     int M, N;
     float eps;
     int nt_store;
+#ifdef VD_TIMELINE
+    unsigned long long* tl;
+#endif
 };
 
 template <bool LN, bool MULTI>
 __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    VD_TL_DECL;
+    VD_TL(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -221,6 +226,9 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();   // ... for every wave; every wave has left K tile kt - 1, whose slot is refilled now
             asm volatile("" ::: "memory");
+#ifdef VD_TIMELINE
+            if (kt == 0) VD_TL(1);
+#endif
             if (kt >= 1 && kt + 2 < RG_KT) issue_kt(kt + 2, (kt + 2) % RG_NSLOT);
             const char* st = smem + (kt % RG_NSLOT) * RG_SLOT;
 #pragma unroll
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
         }
     }
     __syncthreads();   // every wave is done with the slots: the output tile re-uses that LDS
+    VD_TL(2);
 
     // ---- epilogue: + bias -> fp16 tile in LDS -> 16-byte row segments (+ residual) -> y
     f16* cs = reinterpret_cast<f16*>(smem);
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
             *reinterpret_cast<uint2*>(cs + (wm * 32 + l31) * RG_CS_LD + col) = o.u;
         }
     __syncthreads();
+    VD_TL(3);
     constexpr int CH = RG_C / 8;                       // 40 segments per row
     constexpr int PER = RG_BM * CH / 512;              // 10 per thread
 #pragma unroll
@@ -272,6 +282,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
             else *reinterpret_cast<uint4*>(dst) = o.u;
         }
     }
+    VD_TL(4);
+    VD_TL_FLUSH(p.tl);
 }
 
 // ---- vd_gemm_row320_chain_f16: GroupNorm (as a per-sample affine map) -> proj_in -> h, then LayerNorm(h) -> q | k | v, in ONE
@@ -494,6 +506,11 @@ int launch_rowgemm(const RGArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef VD_TIMELINE
+static unsigned long long* g_timeline_row = nullptr;
+extern "C" void vd_debug_set_timeline_row320(void* buf) { g_timeline_row = reinterpret_cast<unsigned long long*>(buf); }
+#endif
+
 extern "C" int vd_gemm_row320_supported(int64_t M, int N, int K) {
     return (K == RG_C && N > 0 && N % RG_C == 0 && M > 0 && M < (1ll << 31) / N) ? 1 : 0;
 }
@@ -507,6 +524,9 @@ extern "C" int vd_gemm_row320_f16(const void* x, const void* w, const void* bias
     RGArgs a;
     a.x = (const f16*)x; a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.y = (f16*)y;
     a.M = (int)M; a.N = N; a.eps = ln_eps;
+#ifdef VD_TIMELINE
+    a.tl = g_timeline_row;
+#endif
     static const char* nt_env = getenv("VD_GEMM_NT");
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
     // more than one column group and no residual: one block per row block walks them all (development switch VD_ROW320_MULTI=0:
