@@ -29,11 +29,15 @@ def rnd(shape, scale, seed):
 
 
 def analyse(tl, name, ev_us):
+    import numpy as np
     t = tl.cpu().numpy().astype("int64")
     t = t[t[:, 0] != 0]
+    if t.shape[0] == 0:
+        print("%s: no stamps (a kernel without them took the launch)" % name)
+        return
+    t[:, 1] = np.maximum(t[:, 1], t[:, 0]); t[:, 2] = np.maximum(t[:, 2], t[:, 1]); t[:, 3] = np.maximum(t[:, 3], t[:, 2])
     t0 = t[:, 0].min()
     span = (t[:, 6].max() - t0) * TICK_US
-    import numpy as np
     ph = {"start offset": t[:, 0] - t0, "prologue (start -> tile 0 landed)": t[:, 1] - t[:, 0], "K loop": t[:, 2] - t[:, 1],
           "epilogue regs -> LDS": t[:, 3] - t[:, 2], "epilogue LDS -> stores issued": t[:, 4] - t[:, 3],
           "stores acknowledged": t[:, 6] - t[:, 4], "block life": t[:, 6] - t[:, 0]}

@@ -474,6 +474,10 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     VD_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "vd_gemm_f16: M=%d is not a multiple of Hout*Wout=%d", d.M, d.Hout * d.Wout);
     if (d.stat_img_rows <= 0) d.stat_img_rows = d.Hout * d.Wout;
     a.stat_rows = 0;
+    {   // development switch VD_GEMM_HOIST=0: epilogue operands are requested behind the main loop (rounds 1-3)
+        static const char* hoist_env = getenv("VD_GEMM_HOIST");
+        a.hoist = (hoist_env && hoist_env[0] == '0') ? 0 : 1;
+    }
 #ifdef VD_TIMELINE
     a.tl = nullptr;
 #endif
@@ -674,10 +678,16 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
             }
         }
         // grids that cannot fill the CUs twice over are latency-bound per block: those get a deeper ring of 64-deep tiles
+        // (round 4, tools/probes/gemm_timeline.py: raising the limit to "every block still co-resident" -- 768 blocks of 64x64,
+        // 512 of 128x64 -- shortens the K loop of the M = 2048, N = K = 1280 projections from 11.6 to 10.1 us per block, not to
+        // half: at 640 blocks x 16 KiB per k-step the loop runs at the L2 -> LDS fill rate, not at one round trip per k-step.
+        // Forward unchanged (10.57 vs 10.57 ms), so the limit stays; VD_GEMM_DEEP_MAX moves it.)
         const long grid_blocks = (long)((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * nsplit * zb;
-        if (grid_blocks <= 400 && ktps >= 8) {
-            if (cfg == T128x64) cfg = T128x64d;
-            else if (cfg == T64x64) cfg = T64x64d;
+        static const char* deep_env = getenv("VD_GEMM_DEEP_MAX");
+        const long deep64 = deep_env ? atol(deep_env) : 400, deep128 = deep_env ? atol(deep_env) : 400;
+        if (ktps >= 8) {
+            if (cfg == T128x64 && grid_blocks <= deep128) cfg = T128x64d;
+            else if (cfg == T64x64 && grid_blocks <= deep64) cfg = T64x64d;
         }
     }
     if (lnfold) {

@@ -51,6 +51,7 @@ struct GemmArgs {
     int mfast;                             // XCD tile runs walk m fastest (tiles of one weight column panel share an L2)
     int stat_rows;                         // d.out_stats: rows per statistics partial (0 = none emitted by this launch)
     int xcd_local;                         // halo conv, ticketed split: the blocks of a tile share an XCD (L2-scope exchange)
+    int hoist;                             // gemm_f16_kernel, small tiles: epilogue operands requested in front of the main loop
 #ifdef VD_TIMELINE
     unsigned long long* tl;                // development build (tools/probes/gemm_timeline.py): 8 stamps per block, or null
 #endif
@@ -121,6 +122,22 @@ __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
     e.act = d.act;
     e.alpha = d.alpha;
     return e;
+}
+
+// bias of 4 consecutive output columns (zeros where there is none / past N)
+__device__ __forceinline__ U2H4 epi_load_bias4(const EpiCtx& e, int N, int col) {
+    U2H4 t;
+    t.u = make_uint2(0, 0);
+    if ((e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M)) {
+        if (col + 4 <= N && (N & 3) == 0) {
+            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col + q < N) t.e[q] = e.bias[col + q];
+        }
+    }
+    return t;
 }
 
 __device__ __forceinline__ float apply_act(int act, float v) {
@@ -391,6 +408,64 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int z = blockIdx.z;
+
+    // Short-lived blocks (the small tiles of the K = 320 .. 1280 projections): the epilogue's operands -- bias, LayerNorm row
+    // statistics, residual / row-vector segments -- are requested HERE, in front of the first K tile, not behind the main loop.
+    // Their round trip was 2.0-2.8 us of a 9-16 us block life (tools/probes/gemm_timeline.py: main loop done -> tile in LDS);
+    // now it overlaps the prologue's.  They are the oldest requests of the wave and loads return in order, so the counted
+    // vmcnt waits of the loop hold unchanged.  Not for launches that leave fp32 partials (split-K) or fp32 output.
+    constexpr int MAX_CH_H = BM * (BN / 8) / NT;
+    constexpr bool HOIST = !MID && EP == 1 && MI * NI <= 2 && MAX_CH_H <= 4;
+    const EpiCtx e = make_epi(d, z);
+    // (32-bit buffer offsets: residual and statistics extents below 2 GiB; vector-aligned rows, as epi_prefetch requires)
+    const bool hoisted = HOIST && gridDim.y == 1 && !(d.flags & VD_EPI_OUT_F32) && d.act != VD_ACT_GEGLU && p.hoist &&
+                         (e.N & 7) == 0 && (e.ldr & 7) == 0 && (unsigned long long)d.M * (unsigned)(e.ldr > e.N ? e.ldr : e.N) < (1ull << 30) &&
+                         (unsigned long long)d.M * (unsigned)(d.batch > 0 ? d.batch : 1) < (1ull << 27);
+    uint4 pre_h[HOIST ? MAX_CH_H : 1];
+    U2H4 bias_h[HOIST ? NI * 4 : 1];
+    float2 lnst_h[HOIST ? MI : 1];
+    if constexpr (HOIST) {
+        // branch-free on purpose: every condition folds into the buffer offset (out of range -> the hardware returns zeros).
+        // With branches around the loads hipcc merged the results through copies and put s_waitcnt vmcnt(0) behind each one.
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const unsigned off_mask = hoisted ? 0u : OOB_OFFSET;
+        const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
+        const bool want_rv = !want_res && (e.flags & VD_EPI_ROWVEC) != 0;
+        const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<f16*>(want_res ? e.res : e.rowvec), 0, (want_res || want_rv) ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < MAX_CH_H; ++k) {
+            const int c = tid + k * NT;
+            const int r = c / (BN / 8), cc = (c % (BN / 8)) * 8;
+            const int row = m0 + r, col = n0 + cc;   // one epilogue pass: tile row r is LDS row r (epi_prefetch with SEG == WM)
+            const bool ok = c < BM * (BN / 8) && row < d.M && col + 8 <= e.N;
+            const unsigned off = want_res ? (unsigned)((row * e.ldr + col) * 2) : (unsigned)(((row / e.rows_per_batch) * e.N + col) * 2);
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_pre, (int)((ok ? off : OOB_OFFSET) | off_mask), 0, 0);
+            pre_h[k] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        const bool want_b = (e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.bias), 0, want_b ? d.N * 2 : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * WN + j * 32 + 8 * g + 4 * hi;   // past N: beyond the descriptor's range -> zeros
+                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (int)((unsigned)(col * 2) | off_mask), 0, 0);
+                bias_h[j * 4 + g].u = make_uint2(v.x, v.y);
+            }
+        if constexpr (LNF) {
+            const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.ln_stats), 0, d.ln_stats != nullptr ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = m0 + wm * WM + i * 32 + l31;
+                const unsigned off = row < d.M ? (unsigned)((z * d.M + row) * 8) : OOB_OFFSET;
+                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs_ln, (int)(off | off_mask), 0, 0);
+                const unsigned vx = v[0], vy = v[1];   // (never __builtin_bit_cast a swizzle: clang reads element 0 for both)
+                lnst_h[i] = make_float2(__uint_as_float(vx), __uint_as_float(vy));
+            }
+        }
+    }
 
     // LayerNorm fold: the block's BN entries of colsum wait in LDS behind the stages / the epilogue tile, so the epilogue's
     // register phase reads them with ds_read instead of one more global round trip per column group
@@ -778,8 +853,6 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
     VD_TL(2);   // main loop done
 
-    const EpiCtx e = make_epi(d, z);
-
     // ---- split-K with arrival counters: every block of a tile leaves its fp32 accumulators in the workspace in REGISTER
     // order ([8-byte group][thread]: fully coalesced, no address arithmetic per element); the block that arrives last sums
     // the slabs in split order (its own included, so the result does not depend on which block that is) and carries on
@@ -886,6 +959,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     }
                 }
         }
+        VD_TL(4);
+        VD_TL_FLUSH(p.tl);
         return;
     }
 
@@ -908,8 +983,18 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     for (int ep = 0; ep < EP; ++ep) {
     if (ep > 0) __syncthreads();  // the previous pass has left the LDS tile
     uint4 pre[MAX_CH];
-    if (geglu) epi_prefetch<PROWS, BN / 16, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
-    else epi_prefetch<PROWS, BN / 8, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+    bool have_pre = false;
+    if constexpr (HOIST) {
+        if (hoisted) {
+#pragma unroll
+            for (int k = 0; k < MAX_CH; ++k) pre[k] = pre_h[k];
+            have_pre = true;
+        }
+    }
+    if (!have_pre) {
+        if (geglu) epi_prefetch<PROWS, BN / 16, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+        else epi_prefetch<PROWS, BN / 8, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+    }
 #pragma unroll
     for (int ii = 0; ii < MIP; ++ii) {
         const int i = ep * MIP + ii;
@@ -929,7 +1014,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 ln_rstd = rsqrtf(var + d.ln_eps);
                 ln_nmr = -mean * ln_rstd;
             } else {
-                const float2 st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
+                float2 st;
+                bool have_st = false;
+                if constexpr (HOIST) {
+                    if (hoisted) { st = lnst_h[i]; have_st = true; }
+                }
+                if (!have_st) st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
                 ln_rstd = st.y;
                 ln_nmr = -st.x * st.y;
             }
@@ -975,16 +1065,14 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     const int col = n0 + lc;
                     float bq[4] = {bm, bm, bm, bm};
                     if ((e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M)) {
-                        if (col + 4 <= d.N && (d.N & 3) == 0) {
-                            U2H4 t;
-                            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (col + q < d.N) bq[q] = (float)e.bias[col + q];
+                        U2H4 t;
+                        bool have_b = false;
+                        if constexpr (HOIST) {
+                            if (hoisted) { t = bias_h[j * 4 + g]; have_b = true; }
                         }
+                        if (!have_b) t = epi_load_bias4(e, d.N, col);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
                     }
                     if (lnf) {   // columns past N hold zeros
                         const float4 c4 = *reinterpret_cast<const float4*>(ln_cs + lc);
