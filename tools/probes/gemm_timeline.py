@@ -80,7 +80,7 @@ def main():
     h.vd_debug_set_timeline_row320.restype = None
     h.vd_debug_set_timeline_row320.argtypes = [ctypes.c_void_p]
     flush = torch.zeros(128 * 1024 * 1024, dtype=torch.float32, device=dev)
-    for (M, C) in ((32768, 320), (8192, 640), (2048, 1280)):
+    for (M, C) in (() if os.environ.get("TL_ONLY", "") == "halo" else ((32768, 320), (8192, 640), (2048, 1280))):
         a = rnd((M, C), 1.0, 1)
         w = rnd((C, C), 0.05, 2)
         b = rnd((C,), 0.1, 3)
@@ -92,6 +92,20 @@ def main():
             fn2 = lambda: ops.gemm_row320(a, w, b, r)   # noqa: E731
             for fl in (None, flush):
                 run("rowgemm320_kernel M=%d N=K=320 +bias +res" % M, fn2, 8192, h.vd_debug_set_timeline_row320, fl)
+    if os.environ.get("TL_ONLY", "") == "halo" or os.environ.get("TL_HALO", "1") != "0":
+        from vd_hip.pack import pack_conv_weight
+        for (B, H, C) in ((8, 64, 320), (8, 32, 640), (8, 16, 1280)):
+            x = rnd((B, H, H, C), 1.0, 11)
+            w = pack_conv_weight(rnd((C, C, 3, 3), 0.02, 12))
+            b = rnd((C,), 0.1, 13)
+            rv = rnd((B, C), 0.3, 14)
+            r = rnd((B, H, H, C), 1.0, 15)
+            fn = lambda: ops.conv2d_nhwc(x, w, b, ksize=3, pad=1, rowvec=rv, rows_per_batch=H * H, want_stats=True)   # noqa: E731
+            run("conv3x3_halo_kernel %dx%d C=%d +bias +rowvec +stats" % (H, H, C), fn, 4096, h.vd_debug_set_timeline, None)
+            fn = lambda: ops.conv2d_nhwc(x, w, b, ksize=3, pad=1, res=r, want_stats=True)   # noqa: E731
+            run("conv3x3_halo_kernel %dx%d C=%d +bias +res +stats" % (H, H, C), fn, 4096, h.vd_debug_set_timeline, flush)
+        if os.environ.get("TL_ONLY", "") == "halo":
+            return
     # a long-K reference: the 16x16-level skip-free 1x1 (K = 2560) and the plain FF-sized projection
     for (M, N, K) in ((8192, 640, 2560), (8192, 5120, 640), (2048, 1280, 5120)):
         a = rnd((M, K), 1.0, 5)

@@ -65,6 +65,8 @@ struct ConvHaloArgs {
 // the same pixels into the same accumulators -- ResBlock's skip_connection(x) + h as extra K of the second conv (d.skip_*).
 template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>
 __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHaloArgs p) {
+    VD_TL_DECL;
+    VD_TL(0);
     constexpr int NW = NT / 64;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == NW, "waves must tile the block");
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        VD_TL(1);   // first halo + weight tiles landed
 #pragma unroll
         for (int i = 0; i < MI; ++i) hrow[i] = hp_base[i];
         {
@@ -530,6 +533,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     }
     wait_vm<0>();
     __syncthreads();   // every wave is done with halo / weight stages: the epilogue tile re-uses that LDS
+    VD_TL(2);
 
     const EpiCtx e = make_epi(d, 0);
     // patch-order row -> output row (pixel index over [image][Hv][Wv])
@@ -656,6 +660,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                     }
                 }
         }
+        VD_TL(4);
+        VD_TL_FLUSH(p.g.tl);
         return;
     }
 
@@ -677,18 +683,28 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     constexpr bool PREFETCH = MAX_CH <= 12;
     constexpr int NPRE = PREFETCH ? MAX_CH : 1;
     uint4 pre[NPRE];
+    // Every operand of the epilogue is requested up front and BRANCH-FREE (buffer loads: an out-of-range offset returns zeros),
+    // so the requests leave back to back.  Rounds 1-3 wrote `if (col < N) pre[k] = *ptr` / `if (bias) t = *ptr`: hipcc put each
+    // load into its own conditional block with s_waitcnt vmcnt(0) behind it -- 10 + 20 SERIAL round trips per block, 11.8 us
+    // (18.6 us with a cold residual) of the 72-us life of a 64x64-level block (tools/probes/gemm_timeline.py).
     if constexpr (PREFETCH) {
+        const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<f16*>(want_res ? e.res : e.rowvec), 0, (ld_ok && (want_res || want_rv) && !HALO_ABL(p, 1)) ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
         for (int k = 0; k < MAX_CH; ++k) {
             const int sgm = tid + k * NT;
             const int r = sgm / CH, col = n0 + (sgm % CH) * 8;
             const int row = out_row(r);
-            pre[k] = make_uint4(0, 0, 0, 0);
-            if (col < e.N && ld_ok && !HALO_ABL(p, 1)) {
-                if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
-                else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)rv_index(r, row) * e.N + col);
-            }
+            const unsigned off = want_res ? (unsigned)((row * e.ldr + col) * 2) : (unsigned)((rv_index(r, row) * e.N + col) * 2);
+            const vd_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_pre, (int)(col < e.N ? off : OOB_OFFSET), 0, 0);
+            pre[k] = make_uint4(v[0], v[1], v[2], v[3]);
         }
+    }
+    U2H4 bias_r[NI * 4];
+    {
+        EpiCtx eb = e;
+        eb.flags &= ~VD_EPI_BIAS_ALONG_M;   // (this kernel has no bias along M)
+        epi_load_bias<NI>(eb, d.N, n0 + wn * WN + 4 * hi, bias_r, true);   // N % 8 == 0 here: whole groups
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -698,14 +714,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int lc = wn * WN + j * 32 + 8 * g + 4 * hi;
-                const int col = n0 + lc;
-                float bq[4] = {0.f, 0.f, 0.f, 0.f};
-                if ((e.flags & VD_EPI_BIAS) && col < d.N) {
-                    U2H4 t;
-                    t.u = *reinterpret_cast<const uint2*>(e.bias + col);
+                float bq[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
-                }
+                for (int q = 0; q < 4; ++q) bq[q] = (float)bias_r[j * 4 + g].e[q];   // zeros without a bias / past N
                 U2H4 o;
                 if (e.act == VD_ACT_NONE) {
 #pragma unroll
@@ -718,6 +729,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             }
     }
     __syncthreads();
+    VD_TL(3);
 
     // ---- part 2: 16-byte row segments: (+ rowvec) (+ residual) -> global
 #pragma unroll
@@ -760,6 +772,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         emit_chan_stats<BN, CS_LD, NT>(cs, reinterpret_cast<float*>(smem + BM * CS_LD * 2), tid, R, nsub, nsub, d.out_stats,
                                        (size_t)tm * nsub, d.N, n0);
     }
+    VD_TL(4);   // (behind the statistics pass where one runs)
+    VD_TL_FLUSH(p.g.tl);
 }
 
 template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>

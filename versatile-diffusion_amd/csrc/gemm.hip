@@ -491,6 +491,11 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     const int n_out = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
     if (d.ldc <= 0) d.ldc = n_out;
     if (d.ldr <= 0) d.ldr = n_out;
+    // the epilogues read residual / row-vector / LayerNorm-statistics through buffer descriptors with 32-bit byte offsets
+    VD_REQUIRE(!(d.flags & VD_EPI_RESIDUAL) || (unsigned long long)d.M * (unsigned)d.ldr < (1ull << 30),
+               "vd_gemm_f16: residual larger than 2 GiB per batch entry (32-bit buffer offsets); split the rows");
+    VD_REQUIRE(!(d.flags & VD_EPI_LNFOLD) || (unsigned long long)d.M * (unsigned)(d.batch > 0 ? d.batch : 1) < (1ull << 27),
+               "vd_gemm_f16: LayerNorm fold over more than 2^27 rows (32-bit buffer offsets); split the rows");
     if (d.batch <= 0) d.batch = 1;
     if (d.flags & VD_EPI_BIAS) VD_REQUIRE(d.bias != nullptr, "vd_gemm_f16: bias flag without pointer");
     if (d.flags & VD_EPI_ROWVEC) VD_REQUIRE(d.rowvec != nullptr && d.rows_per_batch > 0, "vd_gemm_f16: rowvec flag without pointer/rows_per_batch");
@@ -807,6 +812,7 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
     if (rc != VD_OK) return rc;
 #ifdef VD_TIMELINE
     a.tl = g_timeline;
+    halo.g.tl = g_timeline;
 #endif
     const VdGemmDesc& d = a.d;
     if (d.out_stats != nullptr && a.stat_rows == 0) {

@@ -272,23 +272,56 @@ __device__ __forceinline__ void emit_chan_stats(const f16* cs, float* red, int t
 // with both reads the row vector in line.
 // ROWS rows of the LDS tile belong to one epilogue pass; row r of the pass is tile row (r / SEG) * WM + row0 + r % SEG
 // (SEG consecutive rows per wave-row; one pass: SEG = WM, row0 = 0 -> the identity).
+// Branch-free on purpose (round 4): every condition folds into the buffer offset -- an out-of-range offset returns zeros --
+// so the MAX_CH requests leave back to back.  With `if (...) pre[k] = *ptr` hipcc put every load into its own conditional
+// block with s_waitcnt vmcnt(0) behind it: MAX_CH (and, for the bias, 4 x NI) SERIAL round trips per block, 11.8 us of the
+// 72-us life of a 64x64-level conv3x3_halo_kernel block (tools/probes/gemm_timeline.py).  32-bit offsets: the host bounds the
+// residual extent (plan_gemm).  enable = false: nothing is fetched (zeros).
+typedef unsigned int vd_u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int vd_u32x2_t __attribute__((ext_vector_type(2)));
 template <int ROWS, int CH, int NT, int MAX_CH, int SEG, int WM>
-__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, uint4* pre) {
+__device__ __forceinline__ void epi_prefetch(const EpiCtx& e, int M, int m0, int row0, int out_n0, int tid, uint4* pre, bool enable = true) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0);
     const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
     const bool want_rv = !want_res && (e.flags & VD_EPI_ROWVEC) != 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f16*>(want_res ? e.res : e.rowvec), 0, (enable && vec_ok && (want_res || want_rv)) ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
     for (int k = 0; k < MAX_CH; ++k) {
-        pre[k] = make_uint4(0, 0, 0, 0);
         const int c = tid + k * NT;
-        if (vec_ok && c < ROWS * CH) {
-            const int r = c / CH, cc = (c % CH) * 8;
-            const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
-            if (row < M && col + 8 <= e.N) {
-                if (want_res) pre[k] = *reinterpret_cast<const uint4*>(e.res + (size_t)row * e.ldr + col);
-                else if (want_rv) pre[k] = *reinterpret_cast<const uint4*>(e.rowvec + (size_t)(row / e.rows_per_batch) * e.N + col);
-            }
+        const int r = c / CH, cc = (c % CH) * 8;
+        const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
+        const bool ok = c < ROWS * CH && row < M && col + 8 <= e.N;
+        const unsigned off = want_res ? (unsigned)((row * e.ldr + col) * 2) : (unsigned)(((row / e.rows_per_batch) * e.N + col) * 2);
+        const vd_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off : OOB_OFFSET), 0, 0);
+        pre[k] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// bias of the 4 x NI column groups of a lane (columns col0 + j * 32 + 8 g .. + 4) and the LayerNorm-fold row statistics of its
+// MI rows, all requested back to back (see epi_prefetch).  fast = N % 4 == 0 (else zeros: the caller reads the ragged bias
+// element-wise).  Columns past N lie beyond the descriptor's range.
+template <int NI>
+__device__ __forceinline__ void epi_load_bias(const EpiCtx& e, int N, int col0, U2H4* b, bool enable) {
+    const bool want = enable && (e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M) && (N & 3) == 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.bias), 0, want ? N * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const vd_u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (col0 + j * 32 + 8 * g) * 2, 0, 0);
+            b[j * 4 + g].u = make_uint2(v[0], v[1]);
         }
+}
+template <int MI>
+__device__ __forceinline__ void epi_load_lnstats(const float* ln_stats, int M, int z, int row0, float2* st, bool enable) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ln_stats), 0, (enable && ln_stats != nullptr) ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = row0 + i * 32;
+        const vd_u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(row < M ? (unsigned)((z * M + row) * 8) : OOB_OFFSET), 0, 0);
+        const unsigned vx = v[0], vy = v[1];   // (never __builtin_bit_cast a swizzle: clang reads element 0 for both)
+        st[i] = make_float2(__uint_as_float(vx), __uint_as_float(vy));
     }
 }
 
@@ -411,60 +444,23 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
 
     // Short-lived blocks (the small tiles of the K = 320 .. 1280 projections): the epilogue's operands -- bias, LayerNorm row
     // statistics, residual / row-vector segments -- are requested HERE, in front of the first K tile, not behind the main loop.
-    // Their round trip was 2.0-2.8 us of a 9-16 us block life (tools/probes/gemm_timeline.py: main loop done -> tile in LDS);
-    // now it overlaps the prologue's.  They are the oldest requests of the wave and loads return in order, so the counted
-    // vmcnt waits of the loop hold unchanged.  Not for launches that leave fp32 partials (split-K) or fp32 output.
+    // Their round trips were 2.0-2.8 us of a 9-16 us block life (tools/probes/gemm_timeline.py: main loop done -> tile in
+    // LDS); now they overlap the prologue's.  They are the oldest requests of the wave and loads return in order, so the
+    // counted vmcnt waits of the loop hold unchanged.  Blocks that leave fp32 partials never look at them.
     constexpr int MAX_CH_H = BM * (BN / 8) / NT;
-    constexpr bool HOIST = !MID && EP == 1 && MI * NI <= 2 && MAX_CH_H <= 4;
+    // Only where the ~18 registers they occupy across the main loop cost no occupancy: one MFMA tile per wave, no LayerNorm
+    // fold (128x64 on 8 waves with the fold: 78 -> 91 registers, 6 -> 5 waves per SIMD; 128x128 on 8 waves spilled).
+    constexpr bool HOIST = !MID && !LNF && EP == 1 && MI * NI == 1 && MAX_CH_H <= 2;
     const EpiCtx e = make_epi(d, z);
-    // (32-bit buffer offsets: residual and statistics extents below 2 GiB; vector-aligned rows, as epi_prefetch requires)
-    const bool hoisted = HOIST && gridDim.y == 1 && !(d.flags & VD_EPI_OUT_F32) && d.act != VD_ACT_GEGLU && p.hoist &&
-                         (e.N & 7) == 0 && (e.ldr & 7) == 0 && (unsigned long long)d.M * (unsigned)(e.ldr > e.N ? e.ldr : e.N) < (1ull << 30) &&
-                         (unsigned long long)d.M * (unsigned)(d.batch > 0 ? d.batch : 1) < (1ull << 27);
+    const bool hoisted = HOIST && d.act != VD_ACT_GEGLU && p.hoist;
     uint4 pre_h[HOIST ? MAX_CH_H : 1];
-    U2H4 bias_h[HOIST ? NI * 4 : 1];
-    float2 lnst_h[HOIST ? MI : 1];
+    constexpr bool BIAS_ALL = NI <= 2;       // wider wave tiles request the bias per 32-column group (4 requests at a time)
+    U2H4 bias_r[BIAS_ALL ? NI * 4 : 4];
+    float2 lnst_r[MI];
     if constexpr (HOIST) {
-        // branch-free on purpose: every condition folds into the buffer offset (out of range -> the hardware returns zeros).
-        // With branches around the loads hipcc merged the results through copies and put s_waitcnt vmcnt(0) behind each one.
-        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-        const unsigned off_mask = hoisted ? 0u : OOB_OFFSET;
-        const bool want_res = (e.flags & VD_EPI_RESIDUAL) != 0;
-        const bool want_rv = !want_res && (e.flags & VD_EPI_ROWVEC) != 0;
-        const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<f16*>(want_res ? e.res : e.rowvec), 0, (want_res || want_rv) ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < MAX_CH_H; ++k) {
-            const int c = tid + k * NT;
-            const int r = c / (BN / 8), cc = (c % (BN / 8)) * 8;
-            const int row = m0 + r, col = n0 + cc;   // one epilogue pass: tile row r is LDS row r (epi_prefetch with SEG == WM)
-            const bool ok = c < BM * (BN / 8) && row < d.M && col + 8 <= e.N;
-            const unsigned off = want_res ? (unsigned)((row * e.ldr + col) * 2) : (unsigned)(((row / e.rows_per_batch) * e.N + col) * 2);
-            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_pre, (int)((ok ? off : OOB_OFFSET) | off_mask), 0, 0);
-            pre_h[k] = make_uint4(v.x, v.y, v.z, v.w);
-        }
-        const bool want_b = (e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M);
-        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.bias), 0, want_b ? d.N * 2 : 0, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = n0 + wn * WN + j * 32 + 8 * g + 4 * hi;   // past N: beyond the descriptor's range -> zeros
-                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (int)((unsigned)(col * 2) | off_mask), 0, 0);
-                bias_h[j * 4 + g].u = make_uint2(v.x, v.y);
-            }
-        if constexpr (LNF) {
-            const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.ln_stats), 0, d.ln_stats != nullptr ? 0x7fffffff : 0, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = m0 + wm * WM + i * 32 + l31;
-                const unsigned off = row < d.M ? (unsigned)((z * d.M + row) * 8) : OOB_OFFSET;
-                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs_ln, (int)(off | off_mask), 0, 0);
-                const unsigned vx = v[0], vy = v[1];   // (never __builtin_bit_cast a swizzle: clang reads element 0 for both)
-                lnst_h[i] = make_float2(__uint_as_float(vx), __uint_as_float(vy));
-            }
-        }
+        epi_prefetch<BM, BN / 8, NT, MAX_CH_H, WM, WM>(e, d.M, m0, 0, n0, tid, pre_h, hoisted);
+        epi_load_bias<NI>(e, d.N, n0 + wn * WN + 4 * hi, bias_r, hoisted);
+        if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, hoisted);
     }
 
     // LayerNorm fold: the block's BN entries of colsum wait in LDS behind the stages / the epilogue tile, so the epilogue's
@@ -994,7 +990,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     if (!have_pre) {
         if (geglu) epi_prefetch<PROWS, BN / 16, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
         else epi_prefetch<PROWS, BN / 8, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
+        if (ep == 0) {   // bias / LayerNorm statistics of the whole wave tile, requested back to back behind the segments
+            if constexpr (BIAS_ALL) epi_load_bias<NI>(e, d.N, n0 + wn * WN + 4 * hi, bias_r, true);
+            if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, true);
+        }
     }
+    const bool bias_fast = (d.N & 3) == 0;
 #pragma unroll
     for (int ii = 0; ii < MIP; ++ii) {
         const int i = ep * MIP + ii;
@@ -1014,12 +1015,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 ln_rstd = rsqrtf(var + d.ln_eps);
                 ln_nmr = -mean * ln_rstd;
             } else {
-                float2 st;
-                bool have_st = false;
-                if constexpr (HOIST) {
-                    if (hoisted) { st = lnst_h[i]; have_st = true; }
-                }
-                if (!have_st) st = row < d.M ? reinterpret_cast<const float2*>(d.ln_stats)[(size_t)z * d.M + row] : make_float2(0.f, 0.f);
+                const float2 st = lnst_r[i];
                 ln_rstd = st.y;
                 ln_nmr = -st.x * st.y;
             }
@@ -1029,15 +1025,25 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             // tiles of the wave, j = 2jj holds the values and j = 2jj + 1 the gates of output columns jj*32 ..
             if constexpr (NI % 2 == 0) {
 #pragma unroll
-                for (int jj = 0; jj < NI / 2; ++jj)
+                for (int jj = 0; jj < NI / 2; ++jj) {
+                U2H4 bias_v[4], bias_g[4];
+                if constexpr (!BIAS_ALL) {
+                    epi_load_bias<1>(e, d.N, n0 + wn * WN + jj * 64 + 4 * hi, bias_v, true);
+                    epi_load_bias<1>(e, d.N, n0 + wn * WN + jj * 64 + 32 + 4 * hi, bias_g, true);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int lc = wn * (WN / 2) + jj * 32 + 8 * g + 4 * hi;   // column inside the block's output tile
                     const int pn = n0 + wn * WN + jj * 64 + 8 * g + 4 * hi;    // packed weight row of the value element
                     U2H4 bv, bg, o;
-                    bv.u = make_uint2(0, 0);
-                    bg.u = make_uint2(0, 0);
-                    if (e.flags & VD_EPI_BIAS) {
+                    if constexpr (BIAS_ALL) {
+                        bv = bias_r[(2 * jj) * 4 + g];   // packed rows pn .. and pn + 32 ..: column groups 2 jj and 2 jj + 1 of the lane
+                        bg = bias_r[(2 * jj + 1) * 4 + g];
+                    } else {
+                        bv = bias_v[g];
+                        bg = bias_g[g];
+                    }
+                    if ((e.flags & VD_EPI_BIAS) && !bias_fast) {   // packed GEGLU weights have N % 128 == 0: never taken
                         bv.u = *reinterpret_cast<const uint2*>(e.bias + pn);
                         bg.u = *reinterpret_cast<const uint2*>(e.bias + pn + 32);
                     }
@@ -1055,10 +1061,13 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     }
                     *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
                 }
+                }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j) {
+                U2H4 bias_j[4];
+                if constexpr (!BIAS_ALL) epi_load_bias<1>(e, d.N, n0 + wn * WN + j * 32 + 4 * hi, bias_j, true);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int lc = wn * WN + j * 32 + 8 * g + 4 * hi;
@@ -1066,11 +1075,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     float bq[4] = {bm, bm, bm, bm};
                     if ((e.flags & VD_EPI_BIAS) && !(e.flags & VD_EPI_BIAS_ALONG_M)) {
                         U2H4 t;
-                        bool have_b = false;
-                        if constexpr (HOIST) {
-                            if (hoisted) { t = bias_h[j * 4 + g]; have_b = true; }
-                        }
-                        if (!have_b) t = epi_load_bias4(e, d.N, col);
+                        if constexpr (BIAS_ALL) t = bias_r[j * 4 + g];
+                        else t = bias_j[g];
+                        if (!bias_fast) t = epi_load_bias4(e, d.N, col);   // N % 4 != 0: element-wise
 #pragma unroll
                         for (int q = 0; q < 4; ++q) bq[q] = (float)t.e[q];
                     }
@@ -1092,6 +1099,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                     }
                     *reinterpret_cast<uint2*>(cs + lrow_c * CS_LD + lc) = o.u;
                 }
+            }
         }
     }
     __syncthreads();
