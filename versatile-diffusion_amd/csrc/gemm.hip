@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     const int chunks = (d.N + 7) / 8;
     const size_t total = (size_t)d.M * chunks;
     const EpiCtx e = make_epi(d, z);
+    const bool fast = epi8_fast(e);
     for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (size_t)gridDim.x * 256) {
         const int row = (int)(c / chunks);
         const int col = (int)(c - (size_t)row * chunks) * 8;
@@ -27,6 +28,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
         const size_t slab = (size_t)d.M * d.N;
         const float* w0 = d.ws + ((size_t)z * nsplit * d.M + row) * (size_t)d.N + col;
+        Epi8Ops ops;
+        epi8_request(e, row, col, ops, fast);   // (N % 8 == 0: every group is whole) -- in flight across the slab reads
         if (col + 8 <= d.N && (d.N & 3) == 0) {
             int s = 0;
             for (; s + 4 <= nsplit; s += 4) {  // 8 independent 16-byte loads in flight before the adds
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
                 for (int i = 0; i < 8; ++i)
                     if (col + i < d.N) v[i] += w0[(size_t)s * slab + i];
         }
-        epi_store8(e, row, col, v);
+        if (fast) epi8_finish(e, row, col, v, ops);
+        else epi_store8(e, row, col, v);
     }
 }
 
@@ -86,8 +90,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
         const float* w0 = d.ws + (size_t)(row0 + rl) * d.N + col;
+        const bool fast = epi8_fast(e);
+        Epi8Ops ops[RPT];
+        // bias / row vector / residual of the thread's RPT row pieces: in flight across the slab reads
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) epi8_request(e, row0 + rl + LANES * u, col, ops[u], fast);
         int s = 0;
-        for (; s + 2 <= nsplit; s += 2) {   // 4 RPT independent 16-byte loads in flight before the adds (slab order kept)
+        for (; s + 4 <= nsplit; s += 4) {   // 8 RPT independent 16-byte loads in flight before the adds (slab order kept)
+            float4 x[4][RPT], y[4][RPT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    const float* w = w0 + (size_t)(s + t) * slab + (size_t)(LANES * u) * d.N;
+                    x[t][u] = *reinterpret_cast<const float4*>(w);
+                    y[t][u] = *reinterpret_cast<const float4*>(w + 4);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    v[u][0] += x[t][u].x; v[u][1] += x[t][u].y; v[u][2] += x[t][u].z; v[u][3] += x[t][u].w;
+                    v[u][4] += y[t][u].x; v[u][5] += y[t][u].y; v[u][6] += y[t][u].z; v[u][7] += y[t][u].w;
+                }
+        }
+        for (; s + 2 <= nsplit; s += 2) {   // 4 RPT independent 16-byte loads in flight before the adds
             float4 x[2][RPT], y[2][RPT];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -121,7 +148,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
         }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            epi_store8(e, row0 + rl + LANES * u, col, v[u]);   // v: the values before the fp16 store
+            if (fast) epi8_finish(e, row0 + rl + LANES * u, col, v[u], ops[u]);
+            else epi_store8(e, row0 + rl + LANES * u, col, v[u]);   // v: the values before the fp16 store
 #pragma unroll
             for (int i = 0; i < 8; ++i) fin[u][i] = (float)(f16)v[u][i];
         }

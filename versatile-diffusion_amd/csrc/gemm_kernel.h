@@ -209,6 +209,42 @@ __device__ __forceinline__ void epi_store8(const EpiCtx& e, int row, int col, fl
     epi_finish8(e, row, col, v);
 }
 
+// epi_store8 for launches whose 8-column groups are whole and vector-aligned (the split-K reduce kernels): the operands are
+// REQUESTED first, branch-free (epi8_request: three 16-byte buffer loads, a disabled operand has an empty descriptor), and
+// consumed later (epi8_finish), so they overlap the slab reads.  epi_store8 itself reads the bias element by element behind
+// conditions -- hipcc makes that 8 serial round trips per call, ~5 of the 7.7 us of a reduce launch.
+struct Epi8Ops { uint4 bias, rv, res; };
+__device__ __forceinline__ bool epi8_fast(const EpiCtx& e) {
+    return (e.N & 7) == 0 && (e.ldr & 7) == 0 && (e.ldc & 7) == 0 && !(e.flags & (VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M));
+}
+// (enable = false: empty descriptors, zeros -- NOT a branch around the requests: hipcc would wait for each one behind it)
+__device__ __forceinline__ void epi8_request(const EpiCtx& e, int row, int col, Epi8Ops& o, bool enable) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.bias), 0, (enable && (e.flags & VD_EPI_BIAS)) ? e.N * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.rowvec), 0, (enable && (e.flags & VD_EPI_ROWVEC)) ? 0x7fffffff : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(e.res), 0, (enable && (e.flags & VD_EPI_RESIDUAL)) ? 0x7fffffff : 0, 0x00020000);
+    const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs_b, col * 2, 0, 0);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_v, ((row / e.rows_per_batch) * e.N + col) * 2, 0, 0);
+    const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (row * e.ldr + col) * 2, 0, 0);
+    o.bias = make_uint4(b[0], b[1], b[2], b[3]);
+    o.rv = make_uint4(v[0], v[1], v[2], v[3]);
+    o.res = make_uint4(r[0], r[1], r[2], r[3]);
+}
+// v: the reduced accumulators in, the values before the fp16 conversion out (as epi_store8 leaves them)
+__device__ __forceinline__ void epi8_finish(const EpiCtx& e, int row, int col, float* v, const Epi8Ops& o) {
+    U4H8 b, rv, rs, out;
+    b.u = o.bias; rv.u = o.rv; rs.u = o.res;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = apply_act(e.act, v[i] + (float)b.e[i]) * e.alpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (float)rv.e[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += (float)rs.e[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.e[i] = (f16)v[i];
+    *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col) = out.u;
+}
+
 // ---- per-channel statistics of the stored tile for a consuming GroupNorm (VdGemmDesc.out_stats, csrc/gn_fused.hip) ----
 // The fp16 tile cs[rows][CS_LD] holds the FINAL values (part 2 of the epilogue writes what it stores back into the tile).
 // For each of `nsub` blocks of R consecutive tile rows and each of the BN columns: (mean, M2 = sum (x - mean)^2) over the R
