@@ -35,13 +35,21 @@ def analyse(tl, name, ev_us):
     if t.shape[0] == 0:
         print("%s: no stamps (a kernel without them took the launch)" % name)
         return
-    t[:, 1] = np.maximum(t[:, 1], t[:, 0]); t[:, 2] = np.maximum(t[:, 2], t[:, 1]); t[:, 3] = np.maximum(t[:, 3], t[:, 2])
+    if os.environ.get("TL_EPI") != "1":
+        t[:, 1] = np.maximum(t[:, 1], t[:, 0]); t[:, 2] = np.maximum(t[:, 2], t[:, 1]); t[:, 3] = np.maximum(t[:, 3], t[:, 2])
     t0 = t[:, 0].min()
     span = (t[:, 6].max() - t0) * TICK_US
     ph = {"start offset": t[:, 0] - t0, "prologue (start -> tile 0 landed)": t[:, 1] - t[:, 0], "K loop": t[:, 2] - t[:, 1],
           "epilogue regs -> LDS": t[:, 3] - t[:, 2], "epilogue LDS -> stores issued": t[:, 4] - t[:, 3],
           "stores acknowledged": t[:, 6] - t[:, 4], "block life": t[:, 6] - t[:, 0]}
     print("%s: %d blocks, span %.2f us (event timing %.2f us per launch)" % (name, t.shape[0], span, ev_us))
+    if os.environ.get("TL_EPI") == "1":   # -DVD_TIMELINE_EPI build of conv3x3_halo_kernel: slot 1 = epilogue operands arrived, slot 5 = part 2 done
+        ph = {"main loop (start -> done)": t[:, 2] - t[:, 0], "epilogue operands arrive": t[:, 1] - t[:, 2], "regs -> LDS tile": t[:, 3] - t[:, 1],
+              "part 2 (LDS -> stores issued)": t[:, 5] - t[:, 3], "statistics pass": t[:, 4] - t[:, 5], "stores acknowledged": t[:, 6] - t[:, 4]}
+        for k, v in ph.items():
+            v = v * TICK_US
+            print("    %-36s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (k, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+        return
     for k, v in ph.items():
         v = v * TICK_US
         print("    %-36s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (k, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))

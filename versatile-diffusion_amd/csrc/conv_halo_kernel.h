@@ -387,7 +387,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifndef VD_TIMELINE_EPI
         VD_TL(1);   // first halo + weight tiles landed
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) hrow[i] = hp_base[i];
         {
@@ -706,6 +708,13 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         eb.flags &= ~VD_EPI_BIAS_ALONG_M;   // (this kernel has no bias along M)
         epi_load_bias<NI>(eb, d.N, n0 + wn * WN + 4 * hi, bias_r, true);   // N % 8 == 0 here: whole groups
     }
+#if defined(VD_TIMELINE) && defined(VD_TIMELINE_EPI)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VD_TL(1);   // (-DVD_TIMELINE_EPI: slot 1 = the epilogue's operands have arrived)
+#endif
+    // (the activation bodies are compact -- gemm_kernel.h: apply_act -- so the ACT_NONE path of a group hops over ~40
+    // instructions, not over ~400: with the three inlined IEEE-division bodies this loop took 3.8 us for 80 values per lane,
+    // instruction fetch, not arithmetic)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int lrow = wm * WM + i * 32 + l31;
@@ -732,6 +741,36 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     VD_TL(3);
 
     // ---- part 2: 16-byte row segments: (+ rowvec) (+ residual) -> global
+    if (PREFETCH && ld_ok && !(want_res && want_rv) && !HALO_ABL(p, 1)) {
+        auto part2 = [&](auto nt_tag, auto keep_tag) {
+            constexpr bool NTS = decltype(nt_tag)::value, KEEP = decltype(keep_tag)::value;
+#pragma unroll
+            for (int k = 0; k < MAX_CH; ++k) {
+                const int sgm = tid + k * NT;
+                const int r = sgm / CH, cc = (sgm % CH) * 8;
+                const int col = n0 + cc;
+                if (col < e.N) {
+                    const int row = out_row(r);
+                    U4H8 t, a, o;
+                    t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+                    a.u = pre[PREFETCH ? k : 0];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q]);
+                    f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+                    if constexpr (NTS) vd_store16_nt(dst, o.u);
+                    else *reinterpret_cast<uint4*>(dst) = o.u;
+                    if constexpr (KEEP) *reinterpret_cast<uint4*>(cs + r * CS_LD + cc) = o.u;
+                }
+            }
+        };
+        if (p.g.nt_store) {
+            if (want_stats) part2(std::true_type{}, std::true_type{});
+            else part2(std::true_type{}, std::false_type{});
+        } else {
+            if (want_stats) part2(std::false_type{}, std::true_type{});
+            else part2(std::false_type{}, std::false_type{});
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < MAX_CH; ++k) {
         const int sgm = tid + k * NT;
@@ -765,6 +804,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
             }
         }
     }
+    }
+    VD_TL(5);   // part 2 stores issued
     // one partial per patch (a patch lies in one image), or per image where a patch holds several whole small images
     if (want_stats) {
         __syncthreads();

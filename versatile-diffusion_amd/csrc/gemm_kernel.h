@@ -140,11 +140,17 @@ __device__ __forceinline__ U2H4 epi_load_bias4(const EpiCtx& e, int N, int col) 
     return t;
 }
 
+// The three fused activations are all x * sigmoid(s(x)) with s(x) = x (c1 + c3 x^2): quick GELU c1 = 1.702; SiLU c1 = 1; tanh
+// GELU 0.5 x (1 + tanh(u)) = x sigmoid(2 u), c1 = 2 * 0.79788456, c3 = c1 * 0.044715.  One compact body (a multiply-add, v_exp,
+// v_rcp) with the wave-uniform constants in scalar registers, instead of three inlined bodies with IEEE divisions: the
+// epilogues unroll this 16-80 times per lane and the code of the activations NOT taken was what the instruction fetch of
+// the ACT_NONE path hopped over (conv_halo_kernel.h, part 1).
 __device__ __forceinline__ float apply_act(int act, float v) {
-    if (act == VD_ACT_QUICK_GELU) return vd_quick_gelu(v);
-    if (act == VD_ACT_SILU) return vd_silu(v);
-    if (act == VD_ACT_GELU_TANH) return vd_gelu_tanh(v);
-    return v;
+    if (act == VD_ACT_NONE) return v;
+    const float c1 = act == VD_ACT_QUICK_GELU ? 1.702f : (act == VD_ACT_SILU ? 1.0f : 1.5957691216057308f);
+    const float c3 = act == VD_ACT_GELU_TANH ? 0.07135481627260025f : 0.0f;
+    const float sarg = v * fmaf(c3, v * v, c1);
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-sarg));
 }
 
 // Second half of the epilogue for 8 consecutive output columns of one row (values already carry
@@ -367,6 +373,38 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                                              bool nt, bool keep = false) {
     const bool vec_ok = ((e.N & 7) == 0) && ((e.ldr & 7) == 0) && ((e.ldc & 7) == 0);
     const bool both = (e.flags & VD_EPI_RESIDUAL) && (e.flags & VD_EPI_ROWVEC);
+    if (vec_ok && !both) {
+        // the usual case as a compact loop: the uniform decisions (alignment, store policy, write-back) are taken once, so the
+        // unrolled iterations do not hop over the element-wise path they never take (instruction fetch: see conv_halo_kernel.h)
+        auto fast = [&](auto nt_tag, auto keep_tag) {
+            constexpr bool NTS = decltype(nt_tag)::value, KEEP = decltype(keep_tag)::value;
+#pragma unroll
+            for (int k = 0; k < MAX_CH; ++k) {
+                const int c = tid + k * NT;
+                const int r = c / CH, cc = (c % CH) * 8;
+                const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
+                if (c < ROWS * CH && row < M && col < e.N) {
+                    U4H8 t, a, o;
+                    t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+                    a.u = pre[k];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + 0.f);
+                    f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+                    if constexpr (NTS) vd_store16_nt(dst, o.u);
+                    else *reinterpret_cast<uint4*>(dst) = o.u;
+                    if constexpr (KEEP) *reinterpret_cast<uint4*>(cs + r * CS_LD + cc) = o.u;
+                }
+            }
+        };
+        if (nt) {
+            if (keep) fast(std::true_type{}, std::true_type{});
+            else fast(std::true_type{}, std::false_type{});
+        } else {
+            if (keep) fast(std::false_type{}, std::true_type{});
+            else fast(std::false_type{}, std::false_type{});
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < MAX_CH; ++k) {
         const int c = tid + k * NT;
