@@ -12,7 +12,10 @@ import collections, json, re, sqlite3, sys
 def norm(name):
     m = re.search(r"(conv3x3_halo_kernel)<([^>]*)>", name)
     if m:
-        return "%s<%s>" % (m.group(1), ",".join(a.strip() for a in m.group(2).split(",")))
+        args = [a.strip() for a in m.group(2).split(",")]
+        if len(args) == 7:   # the 7th template argument (SKIP: folded skip convolution) is "skip" / absent in the library's names
+            args = args[:6] + (["skip"] if args[6] in ("true", "1") else [])
+        return "%s<%s>" % (m.group(1), ",".join(args))
     if "ff_geglu_kernel" in name:
         return "ff_geglu_kernel"
     m = re.search(r"(gemm_f16_kernel|attn_fwd_kernel)<([^>]*)>", name)

@@ -20,6 +20,10 @@ t = [x for x in tabs if x == "kernels"] or [x for x in tabs if "kernel_dispatch"
 cols = [c[1] for c in cur.execute("pragma table_info('%s')" % t[0])]
 nc = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 key = re.sub(r"\s+", "", want)
+# the library's name of an instantiation -> the demangled kernel name: the halo kernel carries one more template argument
+# (SKIP: the folded skip convolution), printed as false / true
+if key.startswith("conv3x3_halo_kernel<"):
+    key = key[:-len(",skip>")] + ",true>" if key.endswith(",skip>") else key[:-1] + ",false>"
 n, tot = 0, 0
 for s, e, name in cur.execute("select start, end, %s from %s" % (nc, t[0])):
     if key in re.sub(r"\s+", "", name):
