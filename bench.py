@@ -400,6 +400,16 @@ def main():
                                   "on the reference's algorithmic FLOPs"},
     }
     if rank == 0:
+        try:   # which build of the HIP library produced this line (no build_mode record in the tree)
+            from vd_hip.loader import lib_digest, lib_path
+            stamp = lib_path() + ".stamp"
+            out["library"] = {"path": os.path.relpath(lib_path(), ROOT), "digest": lib_digest(),
+                              "source_stamp": (open(stamp).read().strip()[:16] if os.path.exists(stamp) else None),
+                              "mtime": int(os.path.getmtime(lib_path())),
+                              "note": "digest = SHA-256 prefix of libvd_hip.so; source_stamp = hash of csrc/*.hip + headers + build.py "
+                                      "the library was built from (build.py rebuilds when it differs from the sources)"}
+        except Exception as e:
+            out["library"] = {"error": str(e)}
         alg_tf = per_gpu * (2 * n_unet_steps * wl["gf_fwd"] + wl["vae_dec"] + wl["vae_enc"]) / 1e3
         out["algorithmic_tflop_per_step"] = round(alg_tf, 1)
         out["whole_path_tflops_per_gpu"] = round(alg_tf / (ms_per_step / 1e3), 1)

@@ -95,7 +95,17 @@ def test_gemm_asymmetric_identity(ops, dev):
     assert torch.equal(out, w.t().contiguous())
 
 
-@pytest.mark.parametrize("act", ["none", "quick_gelu", "silu"])
+def _act_ref(act, v):
+    if act == "quick_gelu":
+        return v * torch.sigmoid(1.702 * v)
+    if act == "silu":
+        return F.silu(v)
+    if act == "gelu_tanh":
+        return F.gelu(v, approximate="tanh")
+    return v
+
+
+@pytest.mark.parametrize("act", ["none", "quick_gelu", "silu", "gelu_tanh"])
 def test_gemm_epilogue(ops, dev, act):
     M, N, K = 512, 320, 192
     a = rnd((M, K), dev, 1.0, 3)
@@ -103,14 +113,34 @@ def test_gemm_epilogue(ops, dev, act):
     bias = rnd((N,), dev, 0.5, 5)
     res = rnd((M, N), dev, 1.0, 7)
     v = a.float() @ w.float().t() + bias.float()
-    if act == "quick_gelu":
-        v = v * torch.sigmoid(1.702 * v)
-    elif act == "silu":
-        v = F.silu(v)
-    ref = v * 0.7 + res.float()
-    code = {"none": ops.ACT_NONE, "quick_gelu": ops.ACT_QUICK_GELU, "silu": ops.ACT_SILU}[act]
+    ref = _act_ref(act, v) * 0.7 + res.float()
+    code = {"none": ops.ACT_NONE, "quick_gelu": ops.ACT_QUICK_GELU, "silu": ops.ACT_SILU, "gelu_tanh": ops.ACT_GELU_TANH}[act]
     out = ops.gemm(a, w, bias=bias, res=res, act=code, alpha=0.7)
     assert rel_l2(out, ref) < 2e-3
+    # the same through the split-K reduce kernel (its own epilogue: epi8_request / epi8_finish)
+    out = ops.gemm(a, w, bias=bias, res=res, act=code, alpha=0.7, split_k=3)
+    assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "silu", "gelu_tanh"])
+def test_fused_activation_extremes(ops, dev, act):
+    """The fused activations are one body x * sigmoid(x (c1 + c3 x^2)) (gemm_kernel.h: apply_act): pre-activations from -80 to 80
+    (exp overflows to inf on one side, underflows on the other) against torch, through the GEMM and the 3x3 conv epilogues."""
+    from vd_hip.pack import pack_conv_weight
+    code = {"quick_gelu": ops.ACT_QUICK_GELU, "silu": ops.ACT_SILU, "gelu_tanh": ops.ACT_GELU_TANH}[act]
+    M, N, K = 256, 128, 64
+    a = rnd((M, K), dev, 1.0, 31)
+    w = rnd((N, K), dev, 0.02, 32)
+    bias = torch.linspace(-80.0, 80.0, N, device=dev).to(torch.float16)
+    v = a.float() @ w.float().t() + bias.float()
+    out = ops.gemm(a, w, bias=bias, act=code)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - _act_ref(act, v)).abs().max() < 0.06 and rel_l2(out, _act_ref(act, v)) < 2e-3
+    x = rnd((2, 16, 16, 64), dev, 1.0, 33)
+    wt = rnd((N, 64, 3, 3), dev, 0.01, 34)
+    ref = _act_ref(act, _conv_ref(x, wt, bias, 1, 1, 0))
+    out = ops.conv2d_nhwc(x, pack_conv_weight(wt), bias, ksize=3, pad=1, act=code)
+    assert torch.isfinite(out.float()).all() and rel_l2(out, ref) < 2e-3
 
 
 @pytest.mark.parametrize("M,N,rpb", [(512, 320, 128), (384, 1280, 64), (200, 72, 50)])
