@@ -260,13 +260,6 @@ int vd_groupnorm_from_stats_f16(const void* x0, int c0, const float* stats0, int
 int vd_chan_stats_f16(const void* x, long M, int C, int ldx, int rows_per_partial, float* stats, hipStream_t stream);
 int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
                     const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream);
-/* vd_gn_apply_from_stats_f16: vd_gn_table_f32 + vd_gn_apply_table_f16 in ONE launch (every block folds the partials of its
- *   sample's groups into LDS, then streams whole rows); bit-identical to the pair.  Takes the shapes for which
- *   vd_gn_apply_from_stats_ok returns 1 (at most 256 (channel, partial) items per group). */
-int vd_gn_apply_from_stats_ok(int T0, int c0, int T1, int c1, int groups);
-int vd_gn_apply_from_stats_f16(const void* x0, int c0, const float* stats0, int T0, const void* x1, int c1,
-                               const float* stats1, int T1, const void* gamma, const void* beta, void* y, int B, int HW,
-                               int groups, float eps, int apply_silu, hipStream_t stream);
 int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int apply_silu,
                           void* y, hipStream_t stream);
 /* The same map as fp16 [B][C0 + C1] scale / shift vectors: the gn_scale / gn_shift operands of vd_gemm_row320_chain_f16

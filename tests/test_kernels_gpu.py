@@ -930,9 +930,7 @@ def test_chan_stats(ops, dev, B, HW, C, R):
 @pytest.mark.parametrize("B,HW,c0,c1,R0,R1,silu,eps", [
     (2, 4096, 320, 0, 256, 0, True, 1e-5), (2, 4096, 640, 320, 128, 256, True, 1e-5), (3, 1024, 640, 640, 64, 256, True, 1e-5),
     (2, 256, 1280, 1280, 256, 64, True, 1e-5), (4, 64, 1280, 0, 64, 0, False, 1e-6), (2, 4096, 320, 0, 64, 0, False, 1e-6),
-    (1, 1024, 1280, 640, 64, 64, True, 1e-5), (1, 16384, 128, 0, 256, 0, True, 1e-6), (2, 1024, 512, 0, 256, 0, True, 1e-6),
-    (8, 4096, 320, 320, 256, 256, True, 1e-5), (2, 4096, 640, 320, 256, 256, True, 1e-5), (2, 1024, 1280, 1280, 256, 256, True, 1e-5),
-    (2, 1024, 2560, 0, 512, 0, True, 1e-5), (1, 65536, 128, 0, 64, 0, True, 1e-6)])
+    (1, 1024, 1280, 640, 64, 64, True, 1e-5), (1, 16384, 128, 0, 256, 0, True, 1e-6), (2, 1024, 512, 0, 256, 0, True, 1e-6)])
 def test_groupnorm_from_stats(ops, dev, B, HW, c0, c1, R0, R1, silu, eps):
     """vd_groupnorm_from_stats_f16 (partials of either source in its own block size) against torch's GroupNorm; also the
     table form (vd_gn_table_f32 + vd_gn_apply_table_f16) and the dispatch inside ops.groupnorm_silu."""
@@ -952,21 +950,11 @@ def test_groupnorm_from_stats(ops, dev, B, HW, c0, c1, R0, R1, silu, eps):
     table = ops.gn_table(st0, gamma, beta, st1=st1, B=B, groups=32, eps=eps)
     out2 = ops.gn_apply_table(x0, table, x1=x1, silu=silu)
     assert rel_l2(out2, ref) < 2e-3
-    # the pair in one launch (every block folds the partials of its sample's groups itself): bit-identical where it applies
-    fits = ops.gn_apply_from_stats_ok(st0, st1, 32)
-    assert fits == ((C // 32) * max(HW // R0, HW // R1 if c1 else 0) <= 256)
-    if fits:
-        out4 = ops.gn_apply_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu)
-        assert torch.equal(out4, out2)
-    else:
-        from vd_hip import VdHipError
-        with pytest.raises(VdHipError, match="256"):
-            ops.gn_apply_from_stats(x0, gamma, beta, st0, x1=x1, st1=st1, groups=32, eps=eps, silu=silu)
     # dispatch: statistics riding on the tensors (one source measured on the fly when only the other carries them)
     x0._vd_stats = st0
     out3 = ops.groupnorm_silu(x0, gamma, beta, x1=x1, groups=32, eps=eps, silu=silu)
     assert rel_l2(out3, ref) < 2e-3
-    if ops.GN_STATS and not c1:   # the dispatch took the statistics on the tensor: one of the forms, same partials
+    if ops.GN_STATS and not c1:   # the dispatch took the statistics on the tensor: one of the two forms, same partials
         small = B * HW * C <= ops.GN_FUSED_MAX or ops.GN_FORM == "fused"
         assert torch.equal(out3, out if small else out2)
     # run-to-run identical (no atomics)

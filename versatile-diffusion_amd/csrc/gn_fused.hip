@@ -236,134 +236,6 @@ __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a
     }
 }
 
-// ---- 2 + 3 in one launch, ROW-coalesced: every block folds the partials of ALL groups of its sample into scale / shift in
-// LDS (the work of gn_table_kernel, one wave per group, four groups per wave and pass requested in one round trip), then
-// streams whole rows exactly as gn_apply_table_kernel does.  The fold is repeated by every block of the sample (41 KiB of
-// L2-resident partials at the 64x64 level against 16 KiB of x per block) -- cheaper than the launch it replaces: the table
-// kernel is 4.85 us of dispatch + two dependent round trips, 28 times per forward.  Same arithmetic in the same order as
-// gn_table_kernel (one wave per group, lane-strided items, pivot = the group's first partial mean): bit-identical output.
-// Admitted when a group has at most 256 (channel, partial) items (KI = 4 per lane; the VAE's 1024-partial tensors keep the
-// two launches) -- vd_gn_apply_from_stats_ok.
-struct GnRowsArgs {
-    GnTableArgs t;     // table / scale16 / shift16 unused
-    GnApplyArgs ap;    // table unused
-    int mg_T;          // 2^20 / Tmax + 1: idx / Tmax for idx < 256
-};
-
-__global__ __launch_bounds__(256) void gn_apply_from_stats_kernel(const GnRowsArgs p) {
-    extern __shared__ float tab[];   // [2][C]: scale | shift of sample b
-    const GnTableArgs& a = p.t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
-    const int C = a.c0 + a.c1, cg = C / a.groups;
-    const int Tmax = a.T0 > a.T1 ? a.T0 : a.T1;
-    const float n0 = (float)(a.HW / a.T0), n1 = a.T1 > 0 ? (float)(a.HW / a.T1) : 0.f;
-    const int items = cg * Tmax;
-    constexpr int KI = 4, GPW = 4;   // items per lane and group; groups per wave and pass
-    const float2* safe = a.st0 + (size_t)b * a.T0 * a.c0;   // a valid address for the requests that carry no weight
-    for (int g0 = wave; g0 < a.groups; g0 += 4 * GPW) {
-        float2 pv[GPW][KI];
-        float pn[GPW][KI], gam[GPW][2], bet[GPW][2];
-#pragma unroll
-        for (int q = 0; q < GPW; ++q) {
-            const int g = g0 + 4 * q;
-            const bool gv = g < a.groups;
-            const int chp = (gv ? g : 0) * cg;
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {   // branch-free: a request without weight reads `safe`
-                const int idx = lane + k * 64;
-                const int cl = (idx * p.mg_T) >> 20, t = idx - cl * Tmax;
-                const int ch = chp + cl;
-                const bool first = ch < a.c0;
-                const bool ok = gv && idx < items && t < (first ? a.T0 : a.T1);
-                const float2* src = first ? a.st0 + ((size_t)b * a.T0 + t) * a.c0 + ch : a.st1 + ((size_t)b * a.T1 + t) * a.c1 + (ch - a.c0);
-                pv[q][k] = *(ok ? src : safe);
-                pn[q][k] = ok ? (first ? n0 : n1) : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {   // cg <= 128 channels per group
-                const int i = lane + k * 64;
-                const bool ok = gv && i < cg;
-                const int ch = ok ? chp + i : 0;
-                const float gm = (float)a.gamma[ch], bt = (float)a.beta[ch];
-                gam[q][k] = ok ? gm : 0.f;
-                bet[q][k] = ok ? bt : 0.f;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < GPW; ++q) {
-            const int g = g0 + 4 * q;
-            if (g >= a.groups) break;   // wave-uniform
-            const float pivot = __shfl(pv[q][0].x, 0, 64);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < KI; ++k) {
-                const float dm = pv[q][k].x - pivot;
-                s1 += pn[q][k] * dm;
-                s2 += pn[q][k] > 0.f ? pv[q][k].y + pn[q][k] * dm * dm : 0.f;
-            }
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
-            const float ntot = (float)a.HW * (float)cg;
-            const float dmean = s1 / ntot;
-            const float mean = pivot + dmean;
-            const float var = fmaxf(s2 / ntot - dmean * dmean, 0.f);
-            const float rstd = rsqrtf(var + a.eps);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = lane + k * 64;
-                if (i < cg) {
-                    const float sc = rstd * gam[q][k];
-                    tab[g * cg + i] = sc;
-                    tab[C + g * cg + i] = bet[q][k] - mean * sc;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    const GnApplyArgs& x = p.ap;
-    const int C8 = C / 8;
-    const int tc = tid % x.TC, rl = tid / x.TC;
-    if (rl >= x.R) return;
-    const int r0 = blockIdx.x * x.rows_per_chunk;
-    int r1 = r0 + x.rows_per_chunk;
-    if (r1 > x.HW) r1 = x.HW;
-    const size_t rowb = (size_t)b * x.HW;
-    for (int pos = 0; pos < x.npos; ++pos) {
-        const int cc = tc + pos * x.TC;
-        if (cc >= C8) break;
-        const int ch = cc * 8;
-        const float4 s0 = *reinterpret_cast<const float4*>(tab + ch), s1 = *reinterpret_cast<const float4*>(tab + ch + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(tab + C + ch), h1 = *reinterpret_cast<const float4*>(tab + C + ch + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        const bool second = ch >= x.c0;
-        const f16* src = second ? x.x1 + (ch - x.c0) : x.x0 + ch;
-        const int ld = second ? x.c1 : x.c0;
-        for (int r = r0 + rl; r < r1; r += 4 * x.R) {   // 4 loads in flight
-            U4H8 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ru = r + u * x.R;
-                t[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : r)) * ld);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ru = r + u * x.R;
-                if (ru < r1) {
-                    U4H8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float y = fmaf((float)t[u].e[q], sc[q], sf[q]);
-                        o.e[q] = (f16)(x.silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y)) : y);
-                    }
-                    *reinterpret_cast<uint4*>(x.out + (rowb + ru) * C + ch) = o.u;
-                }
-            }
-        }
-    }
-}
-
 // ---- 2 + 3 in one launch: partials -> (mean, rstd) of the block's groups -> normalise (+SiLU) a [rows x slab] panel ------
 // A block owns one sample, a SLAB of S = lcm(channels per group, 8) channels (whole groups, whole 16-byte octets) and a range
 // of rows; it first folds the partials of its S / cg groups (T x S pairs, L2-resident), then streams its panel once.
@@ -569,9 +441,16 @@ static int gn_table_launch(const float* stats0, int T0, int c0, const float* sta
     return vd_check_launch("vd_gn_table_f32");
 }
 
-// apply geometry shared by the two row-coalesced consumers
-static void gn_apply_geometry(GnApplyArgs& a, int C, int HW) {
-    const int C8 = C / 8;
+extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int silu,
+                                     void* out, hipStream_t stream) {
+    VD_REQUIRE(x0 && table && out, "vd_gn_apply_table_f16: null pointer");
+    if (!x1) c1 = 0;
+    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
+    const int C = c0 + c1, C8 = C / 8;
+    VD_REQUIRE(C8 <= 512, "vd_gn_apply_table_f16: C=%d > 4096", C);
+    GnApplyArgs a;
+    a.x0 = reinterpret_cast<const f16*>(x0); a.x1 = reinterpret_cast<const f16*>(x1); a.table = table; a.out = reinterpret_cast<f16*>(out);
+    a.c0 = c0; a.c1 = c1; a.HW = HW; a.silu = silu;
     a.TC = C8 < 256 ? C8 : 256;
     a.R = 256 / a.TC;
     a.npos = (C8 + a.TC - 1) / a.TC;
@@ -583,53 +462,6 @@ static void gn_apply_geometry(GnApplyArgs& a, int C, int HW) {
     rpc = ((rpc + a.R - 1) / a.R) * a.R;
     if (rpc > HW) rpc = HW;
     a.rows_per_chunk = rpc;
-}
-
-extern "C" int vd_gn_apply_from_stats_ok(int T0, int c0, int T1, int c1, int groups) {
-    if (c1 <= 0) { T1 = 0; c1 = 0; }
-    const int C = c0 + c1;
-    if (T0 <= 0 || c0 <= 0 || groups <= 0 || C % groups != 0 || c0 % 8 != 0 || c1 % 8 != 0 || C / 8 > 512) return 0;
-    const int cg = C / groups, Tmax = T0 > T1 ? T0 : T1;
-    return (cg <= 128 && cg * Tmax <= 256) ? 1 : 0;
-}
-
-extern "C" int vd_gn_apply_from_stats_f16(const void* x0, int c0, const float* stats0, int T0, const void* x1, int c1,
-                                          const float* stats1, int T1, const void* gamma, const void* beta, void* y, int B, int HW,
-                                          int groups, float eps, int apply_silu, hipStream_t stream) {
-    VD_REQUIRE(x0 && stats0 && gamma && beta && y, "vd_gn_apply_from_stats_f16: null pointer");
-    if (!x1) { c1 = 0; T1 = 0; stats1 = nullptr; }
-    VD_REQUIRE(c1 == 0 || stats1, "vd_gn_apply_from_stats_f16: second source without statistics");
-    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0, "vd_gn_apply_from_stats_f16: bad sizes");
-    VD_REQUIRE(vd_gn_apply_from_stats_ok(T0, c0, T1, c1, groups), "vd_gn_apply_from_stats_f16: C=%d, %d groups, T=%d/%d: a group must have at most 256 (channel, partial) items (vd_gn_apply_from_stats_ok)", c0 + c1, groups, T0, T1);
-    VD_REQUIRE(HW % T0 == 0 && (c1 == 0 || HW % T1 == 0), "vd_gn_apply_from_stats_f16: partials must tile the %d rows of a sample (T0=%d T1=%d)", HW, T0, T1);
-    const int C = c0 + c1;
-    GnRowsArgs p;
-    p.t.st0 = reinterpret_cast<const float2*>(stats0); p.t.T0 = T0; p.t.c0 = c0;
-    p.t.st1 = reinterpret_cast<const float2*>(stats1); p.t.T1 = T1; p.t.c1 = c1;
-    p.t.gamma = reinterpret_cast<const f16*>(gamma); p.t.beta = reinterpret_cast<const f16*>(beta);
-    p.t.HW = HW; p.t.groups = groups; p.t.eps = eps; p.t.table = nullptr; p.t.scale16 = nullptr; p.t.shift16 = nullptr;
-    p.ap.x0 = reinterpret_cast<const f16*>(x0); p.ap.x1 = reinterpret_cast<const f16*>(x1); p.ap.table = nullptr;
-    p.ap.out = reinterpret_cast<f16*>(y); p.ap.c0 = c0; p.ap.c1 = c1; p.ap.HW = HW; p.ap.silu = apply_silu;
-    gn_apply_geometry(p.ap, C, HW);
-    const int Tmax = T0 > T1 ? T0 : T1;
-    p.mg_T = (1 << 20) / Tmax + 1;
-    hipLaunchKernelGGL(gn_apply_from_stats_kernel, dim3((HW + p.ap.rows_per_chunk - 1) / p.ap.rows_per_chunk, B), dim3(256),
-                       (size_t)2 * C * sizeof(float), stream, p);
-    return vd_check_launch("vd_gn_apply_from_stats_f16");
-}
-
-extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int silu,
-                                     void* out, hipStream_t stream) {
-    VD_REQUIRE(x0 && table && out, "vd_gn_apply_table_f16: null pointer");
-    if (!x1) c1 = 0;
-    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
-    const int C = c0 + c1, C8 = C / 8;
-    VD_REQUIRE(C8 <= 512, "vd_gn_apply_table_f16: C=%d > 4096", C);
-    GnApplyArgs a;
-    a.x0 = reinterpret_cast<const f16*>(x0); a.x1 = reinterpret_cast<const f16*>(x1); a.table = table; a.out = reinterpret_cast<f16*>(out);
-    a.c0 = c0; a.c1 = c1; a.HW = HW; a.silu = silu;
-    gn_apply_geometry(a, C, HW);
-    const int rpc = a.rows_per_chunk;
     hipLaunchKernelGGL(gn_apply_table_kernel, dim3((HW + rpc - 1) / rpc, B), dim3(256), 0, stream, a);
     return vd_check_launch("vd_gn_apply_table_f16");
 }

@@ -70,8 +70,6 @@ PROTOTYPES = {
     "vd_gn_table_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P]),
     "vd_gn_affine_from_stats_f16": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "vd_gn_apply_table_f16": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
-    "vd_gn_apply_from_stats_ok": (_I, [_I, _I, _I, _I, _I]),
-    "vd_gn_apply_from_stats_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vd_row_stats_f16": (_I, [_P, _P, _L, _I, _L, _F, _P]),

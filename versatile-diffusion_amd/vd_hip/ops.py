@@ -557,11 +557,8 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
             # of at most VD_GN_FUSED_MAX elements (small, L2-resident: the two launches are at their ~4.8 us floor each there)
             if GN_FORM == "fused" or B * HW * C <= GN_FUSED_MAX:
                 return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
-            # large tensors: whole rows streamed once, the per-(sample, channel) affine map folded from the partials by every
-            # block itself (one launch) -- or, where a group has too many partials for that (the VAE), by a tiny launch in
-            # front.  (The slab-shaped single launch reads 80-byte pieces and ran no faster than the round-3 pair there.)
-            if GN_APPLY_FUSED and gn_apply_from_stats_ok(st0, st1, groups):
-                return gn_apply_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
+            # default: a tiny launch folds the partials into the per-(sample, channel) affine map, the apply launch streams
+            # whole rows (measured: the slab-shaped single launch reads 80-byte pieces and ran no faster than the old pair)
             table = gn_table(st0, gamma, beta, st1=st1, B=B, groups=groups, eps=eps)
             return gn_apply_table(x, table, x1=x1, silu=silu, out=out)
     if out is None:
@@ -581,7 +578,6 @@ GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
 # (VD_EPI_GROUPNORM).  Correct (test_conv_groupnorm_fused_in_the_reduce) and measured neutral: the panel kernel takes 23.5 us
 # against 13.1 (reduce + statistics) + 9.2 (single-launch norm) -- narrow slabs read partial cache lines (profiles/HISTORY.md)
 GN_REDUCE = os.environ.get("VD_GN_REDUCE", "0") == "1"
-GN_APPLY_FUSED = os.environ.get("VD_GN_APPLY_FUSED", "1") != "0"   # 0: gn_table + gn_apply_table launches for the large tensors
 GN_FUSED_MAX = int(os.environ.get("VD_GN_FUSED_MAX", "2700000"))   # the 16x16 and 8x8 levels (measured: -0.07 ms per forward; 5.3 M: neutral)
 GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
@@ -627,29 +623,6 @@ def groupnorm_from_stats(x, gamma, beta, st0, *, x1=None, st1=None, groups=32, e
         _check(lib().vd_groupnorm_from_stats_f16(_ptr(x), c0, _ptr(st0.buf), st0.T, _ptr(x1), c1, _ptr(st1.buf) if st1 is not None else None,
                                                  st1.T if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(out), B, HW, groups,
                                                  float(eps), 1 if silu else 0, _stream()))
-    return out
-
-
-def gn_apply_from_stats_ok(st0, st1=None, groups=32):
-    """True when the one-launch row-coalesced form (vd_gn_apply_from_stats_f16) takes these statistics."""
-    return bool(lib().vd_gn_apply_from_stats_ok(st0.T, st0.C, st1.T if st1 is not None else 0, st1.C if st1 is not None else 0, int(groups)))
-
-
-def gn_apply_from_stats(x, gamma, beta, st0, *, x1=None, st1=None, groups=32, eps=1e-5, silu=True, out=None):
-    """gn_table() + gn_apply_table() in one launch: every block folds the partials of its sample's groups into LDS, then streams
-    whole rows.  Bit-identical to the pair."""
-    _req(x, "x"); _req(x1, "x1"); _req(gamma, "gamma"); _req(beta, "beta")
-    B, c0 = x.shape[0], x.shape[-1]
-    c1 = x1.shape[-1] if x1 is not None else 0
-    HW = x.numel() // (B * c0)
-    if st0.C != c0 or st0.HW != HW or st0.buf.shape[0] != B * st0.T or (x1 is not None and (st1 is None or st1.C != c1 or st1.HW != HW or st1.buf.shape[0] != B * st1.T)):
-        raise VdHipError("gn_apply_from_stats: statistics do not describe the input tensors")
-    if out is None:
-        out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x.device)
-    with _Timed("gn_apply_from_stats_kernel", 0.0, 2.0 * B * HW * (c0 + c1) * 2):
-        _check(lib().vd_gn_apply_from_stats_f16(_ptr(x), c0, _ptr(st0.buf), st0.T, _ptr(x1), c1, _ptr(st1.buf) if st1 is not None else None,
-                                                st1.T if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(out), B, HW, int(groups),
-                                                float(eps), 1 if silu else 0, _stream()))
     return out
 
 
@@ -1037,7 +1010,7 @@ def _guarded(fn):
     return wrapper
 
 
-for _name in ("gemm", "gemm_row320", "row320_chain", "groupnorm_affine", "gn_apply_from_stats", "ff_geglu", "xattn", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
+for _name in ("gemm", "gemm_row320", "row320_chain", "groupnorm_affine", "ff_geglu", "xattn", "row_stats", "linear", "conv2d_nhwc", "groupnorm_silu", "groupnorm0d_silu", "layernorm", "attention", "softmax_rows", "softmax_rows_f32",
               "timestep_embedding", "cfg_ddim_step", "cfg_ddim_step_dev", "q_sample", "nchw_to_nhwc", "nhwc_to_nchw",
               "im2col_small", "diag_gaussian_sample", "axpby", "embed_tokens", "clip_vision_embed", "patchify",
               "unary", "scale_by_row_norm_", "image_to_u8", "clip_preprocess", "probe_lds_tr16", "mask_patch_weights", "color_adjust", "adjust_rank"):
