@@ -214,3 +214,42 @@ def test_wreg_column_tiling_covers_the_output_widths():
     assert sup == 1 and 4 <= ns <= 6 and rows == 64  # 16 patches x 3 tiles
     assert plan(8, 16, 1280, 1280, ws=False)[1] == 1 # no workspace: no split
     assert plan(8, 24, 64, 320)[0] == 0              # 24 x 24 grid does not tile into 128-pixel patches
+
+
+def test_which_convolutions_take_the_folded_skip_convolution():
+    """vd_gemm_skip_ok: ResBlock's skip 1x1 convolution rides as extra K of the second 3x3 conv where the halo-resident kernel
+    takes the launch (its SKIP instance, variant 12); the 8x8 level and the upsampling / strided convs do not -- there the caller
+    runs the 1x1 convolution itself (the weight-streaming kernel has its own entry, vd_conv3x3_wstream_f16)."""
+    from vd_hip.loader import VdGemmDesc, lib
+    assert lib().vd_conv_halo_set_variant(-1) == 0
+
+    def ok(B, h, c, cs0, cs1, ups=0, stride=1, res=False):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = B * (h << ups) ** 2 // (stride * stride), c, 9 * c
+        d.a0 = d.w = d.out = d.ws = 16
+        d.Hin = d.Win = h
+        d.Hout = d.Wout = (h << ups) // stride
+        d.ksize, d.stride, d.pad, d.ups, d.c0 = 3, stride, 1, ups, c
+        d.skip_a0, d.skip_w, d.skip_c0 = 16, 16, cs0
+        if cs1:
+            d.skip_a1, d.skip_c1 = 16, cs1
+        if res:
+            d.res, d.flags = 16, 8   # VD_EPI_RESIDUAL
+        return lib().vd_gemm_skip_ok(ctypes.byref(d))
+
+    assert ok(8, 64, 320, 640, 320) == 1      # output block at the 64x64 level
+    assert ok(8, 32, 640, 1280, 640) == 1     # 32x32: split over chunks, the skip chunks shared between the splits
+    assert ok(8, 16, 1280, 1280, 1280) == 1
+    assert ok(8, 32, 640, 320, 0) == 1        # input block 4: single source
+    assert ok(8, 8, 1280, 1280, 1280) == 0    # 8x8 level: gemm_f16_kernel / the weight stream, not the halo kernel
+    assert ok(8, 32, 640, 640, 0, ups=1) == 0   # Upsample conv: no skip path in the upsampling instance
+    assert ok(8, 64, 320, 100, 0) == 0        # channels not a multiple of 64
+    cfg = ctypes.c_int(-1); ns = ctypes.c_int(-1)
+    d = VdGemmDesc()
+    d.M, d.N, d.K = 32768, 320, 2880
+    d.a0 = d.w = d.out = d.ws = 16
+    d.Hin = d.Win = d.Hout = d.Wout = 64
+    d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, 320
+    d.skip_a0, d.skip_w, d.skip_c0 = 16, 16, 640
+    assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+    assert cfg.value == NCFG + 12 and lib().vd_gemm_config_name(cfg.value) == b"conv3x3_halo_kernel<256,160,32,160,512,2,skip>"
