@@ -86,6 +86,24 @@ def test_gemm_plain(ops, dev, M, N, K):
     assert rel_l2(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 100, 64), (300, 102, 64), (64, 4, 128), (1000, 36, 320), (130, 90, 1280)])
+def test_gemm_epilogue_unaligned_widths(ops, dev, M, N, K):
+    """Output widths that are not multiples of 8 (and of 4): the epilogue's requests fall back from the 16-byte segment /
+    8-byte bias-group forms to the element-wise tail -- bias, per-sample row vector and residual must still all arrive."""
+    a = rnd((M, K), dev, 1.0, 81)
+    w = rnd((N, K), dev, 0.05, 82)
+    bias = rnd((N,), dev, 0.5, 83)
+    res = rnd((M, N), dev, 1.0, 84)
+    ref = a.float() @ w.float().t() + bias.float()
+    assert rel_l2(ops.gemm(a, w, bias=bias), ref) < 2e-3
+    assert rel_l2(ops.gemm(a, w, bias=bias, res=res), ref + res.float()) < 2e-3
+    rpb = M // 2 if M % 2 == 0 else M
+    rv = rnd((M // rpb, N), dev, 0.5, 85)
+    out = ops.gemm(a, w, bias=bias, rowvec=rv, rows_per_batch=rpb, res=res)
+    assert rel_l2(out, ref + rv.float().repeat_interleave(rpb, 0) + res.float()) < 2e-3
+    assert rel_l2(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU, res=res), F.silu(ref) + res.float()) < 2e-3
+
+
 def test_gemm_asymmetric_identity(ops, dev):
     """A = I with an asymmetric W catches row/col swaps in the C write (guide rule: transpose-detecting)."""
     K = 128
