@@ -176,6 +176,14 @@ int vd_conv_halo_set_variant(int setting);
  * skip_c1) is taken too: desc->skip_w then holds the 1x1 weights in fragment order, fp16 [N / 32][(skip_c0 + skip_c1) / 64][4]
  * [64 lanes][8] (pack_linear_weight_stream).  vd_conv3x3_wstream_supported: 1 when desc's geometry fits. */
 int vd_conv3x3_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
+/* vd_gemm_wstream_f16: plain GEMM y = x W^T (+ fused epilogue of the descriptor) for long-K, small-M projections -- the output
+ * projection of the gated feed-forward at the 16x16 / 8x8 levels (lib/model_zoo/attention.py:37-64, FeedForward.net[2]) -- with
+ * the weights in MFMA-fragment order (w_stream: fp16 [N / 32][K / 64][4][64 lanes][8], pack_linear_weight_stream) streamed
+ * straight into registers; only the activation tile takes the LDS path.  Split over K in 64-deep chunks + the split-K reduce
+ * (needs desc->ws, vd_gemm_workspace_bytes).  vd_gemm_wstream_supported: 1 when desc's shape fits (single source, M % 128 ==
+ * 0, N % 256 == 0, K % 64 == 0, plain fp16 epilogue). */
+int vd_gemm_wstream_supported(const VdGemmDesc* desc);
+int vd_gemm_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
 int vd_conv3x3_wstream_supported(const VdGemmDesc* desc);
 /* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */
 int vd_conv3x3_wstream_set_variant(int variant, int target_blocks);

@@ -1132,6 +1132,35 @@ def test_conv3x3_wstream_with_folded_skip_conv(ops, dev, case):
     assert ops.conv2d_nhwc(h, wp, b, ksize=3, pad=1, w_stream=wsm, skip=(s0, s1, w1)) is None
 
 
+@pytest.mark.parametrize("M,N,K,split", [(2048, 1280, 5120, 0), (512, 1280, 5120, 0), (128, 256, 64, 0), (256, 512, 2560, 0),
+                                         (384, 256, 4096, 2), (128, 768, 3072, 1), (1024, 256, 2112, 0)])
+def test_gemm_wstream(ops, dev, M, N, K, split):
+    """vd_gemm_wstream_f16 (weights in MFMA-fragment order streamed into registers, activation tile through LDS, split over
+    64-deep chunks + reduce) against torch fp32 and against gemm_f16_kernel: bias, residual, activation; one chunk per block up
+    to the 32 the kernel unrolls (K = 2112 in one split = 33 chunks: the launcher must split)."""
+    from vd_hip.pack import pack_linear_weight_stream
+    a = rnd((M, K), dev, 1.0, 740)
+    w = rnd((N, K), dev, 0.03, 741)
+    b = rnd((N,), dev, 0.3, 742)
+    res = rnd((M, N), dev, 1.0, 743)
+    ws = pack_linear_weight_stream(w)
+    ref = a.float() @ w.float().t() + b.float()
+    out = ops.gemm(a, w, bias=b, w_stream=ws, split_k=split)
+    assert out.shape == (M, N) and rel_l2(out, ref) < 2e-3
+    names = []
+    ops.profile_begin()
+    out = ops.gemm(a, w, bias=b, res=res, w_stream=ws, split_k=split)
+    names = [n for n, _, _, _ in ops.profile_end()]
+    assert any("gemm_wstream" in n for n in names), names
+    assert rel_l2(out, ref + res.float()) < 2e-3
+    assert rel_l2(out, ops.gemm(a, w, bias=b, res=res)) < 2e-3
+    out = ops.gemm(a, w, bias=b, res=res, act=ops.ACT_SILU, alpha=0.5, w_stream=ws, split_k=split)
+    assert rel_l2(out, F.silu(ref) * 0.5 + res.float()) < 2e-3
+    # shapes the kernel does not take fall through to gemm_f16_kernel
+    out = ops.gemm(a[:100], w, bias=b, w_stream=ws)
+    assert rel_l2(out, ref[:100]) < 2e-3
+
+
 def test_blocks_are_placed_round_robin_over_the_xcds(ops, dev):
     """Block b of the linearised grid runs on XCD b % 8 (up to a rotation): what the XCD-aware tile orders assume for
     locality, and what the ticketed split of conv3x3_halo_kernel relies on for CORRECTNESS -- with a tile count that is a

@@ -3,6 +3,7 @@
 // weight fragments in flight, the pixel fragments and the addresses.
 #include "conv_wstream_kernel.h"
 #include "conv_wreg_kernel.h"
+#include "gemm_wstream_kernel.h"
 
 // gemm.hip
 int vd_gemm_normalise(const VdGemmDesc* desc, void* gemm_args_out);
@@ -121,6 +122,68 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
         case 3: lrc = launch_wstream<6, 2>(w, tiles * nsplit, stream); break;
         default: lrc = launch_wstream<12, 1>(w, tiles * nsplit, stream); break;
     }
+    if (lrc != VD_OK) return lrc;
+    return vd_gemm_launch_reduce(&a, nsplit, stream);
+}
+
+
+// ---- weight-streaming GEMM for the long-K, small-M projections (gemm_wstream_kernel.h) ----------------------------------
+namespace {
+const char* gw_reject(const VdGemmDesc& d) {
+    if (d.ksize > 1 || d.stride > 1 || d.pad != 0 || d.ups != 0 || d.batch != 1 || d.a1 != nullptr) return "a plain single-source, unbatched GEMM";
+    if (d.M % 128 != 0 || d.N % 256 != 0 || d.K % 64 != 0) return "M % 128 == 0, N % 256 == 0, K % 64 == 0";
+    if ((d.flags & (VD_EPI_LNFOLD | VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M)) || d.act == VD_ACT_GEGLU) return "a plain fp16 epilogue";
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int vd_gemm_wstream_supported(const VdGemmDesc* dp) {
+    if (dp == nullptr) return 0;
+    VdGemmDesc d = *dp;
+    if (d.batch <= 0) d.batch = 1;
+    return gw_reject(d) == nullptr ? 1 : 0;
+}
+
+extern "C" int vd_gemm_wstream_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
+    VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_gemm_wstream_f16: null argument");
+    VdGemmDesc tmp = *dp;
+    tmp.w = w_stream;          // the K-contiguous weights are not read on this path
+    tmp.out_stats = nullptr;   // (validated below, not by the planner of the other kernels)
+    GemmArgs a;
+    const int rc = vd_gemm_normalise(&tmp, &a);
+    if (rc != VD_OK) return rc;
+    VdGemmDesc& d = a.d;
+    const char* why = gw_reject(d);
+    VD_REQUIRE(why == nullptr, "vd_gemm_wstream_f16 takes %s", why ? why : "");
+    VD_REQUIRE(d.ws != nullptr, "vd_gemm_wstream_f16: needs the split-K workspace (vd_gemm_workspace_bytes)");
+    VD_REQUIRE(((size_t)w_stream & 15) == 0 && d.lda0 % 8 == 0, "vd_gemm_wstream_f16: w_stream must be 16-byte aligned, lda a multiple of 8");
+    d.out_stats = dp->out_stats;
+    d.sync = nullptr;
+    if (d.out_stats != nullptr)
+        VD_REQUIRE(d.N % 8 == 0 && d.ldc % 8 == 0 && (!(d.flags & VD_EPI_RESIDUAL) || d.ldr % 8 == 0) && ((size_t)d.out_stats & 7) == 0 && d.M % 64 == 0,
+                   "vd_gemm_wstream_f16: out_stats needs 16-byte row segments");
+    a.stat_rows = d.out_stats ? 64 : 0;
+    GwArgs w;
+    w.a = reinterpret_cast<const f16*>(d.a0); w.wp = reinterpret_cast<const uint4*>(w_stream); w.ws = d.ws;
+    w.lda = d.lda0; w.M = d.M; w.N = d.N;
+    w.nchunks = d.K / 64;
+    w.tiles_m = d.M / 128; w.tiles_n = d.N / 256;
+    w.a_bytes = a.a0_bytes;
+    // split over the chunks until about one block per CU (a block = four waves, one per SIMD)
+    const int tiles = w.tiles_m * w.tiles_n;
+    static const char* tgt_env = getenv("VD_GEMM_WSTREAM_BLOCKS");
+    const int target = tgt_env ? atoi(tgt_env) : 256;
+    int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > w.nchunks) nsplit = w.nchunks;
+    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
+    if ((w.nchunks + nsplit - 1) / nsplit > GW_MAXC) nsplit = (w.nchunks + GW_MAXC - 1) / GW_MAXC;   // the kernel unrolls its chunks
+    VD_REQUIRE(nsplit <= VD_MAX_SPLIT_K, "vd_gemm_wstream_f16: K = %d needs more than %d splits", d.K, VD_MAX_SPLIT_K);
+    w.cps = (w.nchunks + nsplit - 1) / nsplit;
+    nsplit = (w.nchunks + w.cps - 1) / w.cps;
+    w.nsplit = nsplit;
+    hipLaunchKernelGGL(gemm_wstream_kernel, dim3(tiles * nsplit), dim3(256), 2 * GW_TILE, stream, w);
+    const int lrc = vd_check_launch("vd_gemm_wstream_f16");
     if (lrc != VD_OK) return lrc;
     return vd_gemm_launch_reduce(&a, nsplit, stream);
 }

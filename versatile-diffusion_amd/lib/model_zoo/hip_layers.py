@@ -114,8 +114,19 @@ class Linear(nn.Linear, PackCache):
     def _w(self):
         return self._packed("w", (self.weight, self.bias), lambda: (_h(self.weight), _h(self.bias)))
 
+    def _w_stream(self):
+        """The weight in MFMA-fragment order for vd_gemm_wstream_f16 (long-K projections applied to few rows)."""
+        return self._packed("w_stream", (self.weight,), lambda: pack.pack_linear_weight_stream(_h(self.weight)))
+
     def forward(self, x, **epi):
         w, b = self._w()
+        # long-K, small-M: the layer is its weight stream (FeedForward's output projection at the 16x16 / 8x8 levels: 5120 ->
+        # 1280 against 2048 / 512 rows) -- fragments straight into registers instead of both operands through LDS
+        if (ops.GEMM_WSTREAM and self.in_features >= 2048 and self.in_features % 64 == 0 and self.out_features % 256 == 0
+                and not epi.get("want_stats") and epi.get("colsum") is None and epi.get("rowvec") is None):
+            m = x.numel() // x.shape[-1]
+            if m % 128 == 0 and m <= 4096:
+                epi = dict(epi, w_stream=self._w_stream())
         return ops.linear(x, w, b, **epi)
 
 

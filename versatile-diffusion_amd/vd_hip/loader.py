@@ -46,6 +46,8 @@ PROTOTYPES = {
     "vd_gemm_groupnorm_ok": (_I, [ctypes.POINTER(VdGemmDesc), _I]),
     "vd_gemm_skip_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
+    "vd_gemm_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
+    "vd_gemm_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),
     "vd_conv3x3_wreg_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),

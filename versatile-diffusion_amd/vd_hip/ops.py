@@ -306,6 +306,22 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if fused_gn:
             out._vd_normalized = True
         return out
+    if (w_stream is not None and GEMM_WSTREAM and conv is None and a1 is None and colsum is None and rowvec is None and skip is None
+            and not want_stats and max(batch, 1) == 1 and lib().vd_gemm_wstream_supported(ctypes.byref(d))):
+        # long-K, small-M projection: weights in fragment order straight into registers (gemm_wstream_kernel.h) + reduce
+        _req(w_stream, "w_stream")
+        d.split_k = int(split_k)
+        d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+        stats = None
+        nm = "gemm_wstream_kernel + reduce"
+        if PROFILE_SHAPES:
+            nm += " M=%d N=%d K=%d" % (M, N, K)
+        extra = float(M) * n_out if res is not None else 0.0
+        with _Timed(nm, 2.0 * M * N * K, 2.0 * (float(M) * K + float(N) * K + float(M) * n_out + extra)):
+            _check(lib().vd_gemm_wstream_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
+        if stats is not None:
+            out._vd_stats = stats
+        return out
     if w_stream is not None and WREG and skip is None and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
         # weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h): plan first (split factor -> workspace,
         # rows per statistics partial), then launch
@@ -395,6 +411,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
 SKIP_FOLD = os.environ.get("VD_SKIP_FOLD", "1") != "0"   # ResBlock skip 1x1 convolution as extra K of the second 3x3 conv
 WREG = os.environ.get("VD_WREG", "0") == "1"   # 3x3 convolutions on the weights-in-registers kernel where its geometry fits
 WREG_MIN_M = int(os.environ.get("VD_WREG_MIN_M", "0"))
+GEMM_WSTREAM = os.environ.get("VD_GEMM_WSTREAM", "1") != "0"   # long-K small-M Linear layers on gemm_wstream_kernel (FeedForward out at 16x16 / 8x8)
 WSTREAM = os.environ.get("VD_WSTREAM", "1") != "0"   # development switch: 0 = the 8x8-level 3x3 convolutions stay on gemm_f16_kernel
 ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
 
