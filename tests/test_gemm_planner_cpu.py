@@ -253,3 +253,25 @@ def test_which_convolutions_take_the_folded_skip_convolution():
     d.skip_a0, d.skip_w, d.skip_c0 = 16, 16, 640
     assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
     assert cfg.value == NCFG + 12 and lib().vd_gemm_config_name(cfg.value) == b"conv3x3_halo_kernel<256,160,32,160,512,2,skip>"
+
+
+def test_which_projections_take_the_weight_streaming_gemm():
+    """vd_gemm_wstream_supported: plain single-source GEMMs with whole 128-row / 256-column tiles and 64-deep chunks of K and a
+    plain fp16 epilogue (the FF-out projection of the deep levels); everything else stays on gemm_f16_kernel."""
+    from vd_hip.loader import VdGemmDesc, lib
+
+    def ok(M, N, K, **kw):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.a0 = d.w = d.out = d.ws = 16
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib().vd_gemm_wstream_supported(ctypes.byref(d))
+
+    assert ok(2048, 1280, 5120) == 1 and ok(512, 1280, 5120) == 1 and ok(128, 256, 64) == 1
+    assert ok(2048, 640, 2560) == 0          # N = 640: no whole 256-column tiles (the 32x32 level stays on gemm_f16_kernel)
+    assert ok(2000, 1280, 5120) == 0         # ragged rows
+    assert ok(2048, 1280, 5100) == 0         # K not in 64-deep chunks
+    assert ok(2048, 1280, 5120, act=1) == 0  # GEGLU epilogue
+    assert ok(2048, 1280, 5120, a1=16, c1=64) == 0   # two-source A
+    assert ok(2048, 1280, 5120, ksize=3, stride=1, pad=1) == 0
