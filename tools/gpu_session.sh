@@ -11,6 +11,8 @@
 #   trace                          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.csv / breakdown
 #   pmc                            FETCH_SIZE / WRITE_SIZE passes over the forward -> pmc_traffic.json
 #   py:<script and args>           python tools/<script> (commas separate arguments)
+#   rtrace:<script,args>           rocprofv3 --kernel-trace --stats of a tool -> per-kernel averages
+#   rpmc:<CTR+CTR>;<script,args>   one rocprofv3 --pmc pass over a tool -> per-kernel counter means
 cd "$(dirname "$0")/.." && export VD_QUIET=1
 R=$PWD; O=$R/gpurun_out/$1; shift; mkdir -p $O
 envrun() {   # envrun "A=1,B=2" cmd...
@@ -61,6 +63,17 @@ for step in "$@"; do
         F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
         python tools/pmc_traffic.py $F $W > $O/pmc_traffic.json 2> $O/pmc_traffic.err; echo "traffic rc=$? $(wc -c < $O/pmc_traffic.json) bytes"
         rm -rf $O/pmc_fetch $O/pmc_write ;;
+    rtrace)   # rtrace:<script,args>   rocprofv3 --kernel-trace --stats of python tools/<script> -> per-kernel averages
+        (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o t -- python $R/tools/$(echo "$arg" | tr ',' ' ') > $O/$tag.log 2>&1); echo "rc=$?"
+        DB=$(find $O/prof_$n -name "*.db" | head -1)
+        python tools/kernel_stats.py $DB > $O/$tag.csv 2> $O/$tag.err; head -40 $O/$tag.csv | cut -c1-200
+        rm -rf $O/prof_$n ;;
+    rpmc)     # rpmc:<CTR+CTR+...>;<script,args>   one counter pass (no trace domains besides the kernel trace) -> per-kernel means
+        ctrs="${arg%%;*}"; scr="${arg#*;}"
+        (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $(echo "$ctrs" | tr '+' ' ') -d $O/prof_$n -o c -- python $R/tools/$(echo "$scr" | tr ',' ' ') > $O/$tag.log 2>&1); echo "rc=$?"
+        DB=$(find $O/prof_$n -name "*.db" | head -1)
+        python tools/pmc_summary.py $DB > $O/$tag.txt 2> $O/$tag.err; head -60 $O/$tag.txt | cut -c1-160
+        rm -rf $O/prof_$n ;;
     py)
         timeout 900 python tools/$(echo "$arg" | tr ',' ' ') > $O/$tag.log 2>&1; echo "rc=$?"; tail -25 $O/$tag.log ;;
     *) echo "unknown step $step" ;;

@@ -28,6 +28,9 @@ class DDIMSampler(object):
         self.use_graph = os.environ.get("VD_DDIM_GRAPH", "1") != "0"
         self.graph_cache = os.environ.get("VD_DDIM_GRAPH_CACHE", "1") != "0"   # keep captured steps across sample() calls
         self.replay_first = os.environ.get("VD_DDIM_REPLAY_FIRST", "1") != "0"   # with a kept graph step 0 is replayed too
+        # the t-only part of the UNet (time-embedding MLP + every ResBlock's emb_layers projection) for all steps at once,
+        # outside the step graph (VD_v2_0.precompute_step_emb); 0 = recompute it inside every step like the reference
+        self.emb_hoist = os.environ.get("VD_EMB_HOIST", "1") != "0"
         self._static = {}
         # one request at a time per sampler: the kept step graphs read and write static buffers (the reference's sampler is
         # not re-entrant either, but it has no captured state to corrupt; app.py runs Gradio workers unlocked)
@@ -223,11 +226,28 @@ class DDIMSampler(object):
                 replay_first = True
         table = self._coef_table(total_steps, scale, dev)
         steps_dev = torch.from_numpy(np.ascontiguousarray(time_range).astype(np.int64)).to(dev)
+        # every sample of the batch is at the same timestep in every step, and all steps are known now: the t-only part of the
+        # forward (reference vd.py:339-349 -> openaimodel.py:2627-2633, :263) is computed here for all of them (M = steps
+        # instead of `steps` times M = batch) and the step reads row i from a static buffer
+        emb_tab = emb_rows = embrow = None
+        if self.emb_hoist and hasattr(self.model, "precompute_step_emb"):
+            pre = self.model.precompute_step_emb(x_info["type"], steps_dev, multicontext=not single)
+            if pre is not None:
+                emb_tab, layout = pre
+                embrow = st.get("embrow") if st is not None else None
+                if embrow is None or embrow.numel() != emb_tab.shape[1]:
+                    assert graph is None, "the kept step graph reads another time-embedding buffer"
+                    embrow = torch.empty((emb_tab.shape[1],), device=dev, dtype=torch.float16)
+                    if st is not None:
+                        st["embrow"] = embrow
+                emb_rows = {di: embrow[o:o + c] for di, (o, c) in layout.items()}
 
         def body():
             # guided: the UNet batch is [xs; xs] (ddim.py:144-149).  It is handed over as (xs, repeat=2) so the data blocks in
             # front of the first context block run once (extension key of this package's apply_model*)
             xi = {"type": x_info["type"], "x": xs, "repeat": 2 if guided else 1}
+            if emb_rows is not None:
+                xi["emb_rows"] = emb_rows
             if single:
                 eps = self.model.apply_model(xi, ts, c_info_list[0])
             else:
@@ -247,6 +267,8 @@ class DDIMSampler(object):
             index = total_steps - i - 1
             ts.copy_(steps_dev[i].expand(nb))       # device-side refresh, no host sync
             coef.copy_(table[index])
+            if embrow is not None:
+                embrow.copy_(emb_tab[i])
             if (i == 0 and not replay_first) or not self.use_graph:
                 body()
             elif graph is None:

@@ -41,9 +41,11 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     channels-last extras: `skip` (tensor concatenated on channels in place), the context K/V cache and the
     mixing epilogue."""
 
-    def forward(self, x, emb, context=None, skip=None, emb_out=None, **ctx_kw):
+    def forward(self, x, emb, context=None, skip=None, emb_out=None, emb_bias=None, **ctx_kw):
         for layer in self:
-            if isinstance(layer, TimestepBlock):
+            if isinstance(layer, ResBlock):
+                x = layer(x, emb, skip=skip, emb_out=emb_out, emb_bias=emb_bias)
+            elif isinstance(layer, TimestepBlock):
                 x = layer(x, emb, skip=skip, emb_out=emb_out)
             elif isinstance(layer, SpatialTransformer):
                 x = layer(x, context, **ctx_kw)
@@ -130,13 +132,18 @@ class ResBlock(TimestepBlock, PackCache):
         else:
             self.skip_connection = Conv2d(channels, self.out_channels, 1)
 
-    def forward(self, x, emb_silu, skip=None, emb_out=None):
+    def forward(self, x, emb_silu, skip=None, emb_out=None, emb_bias=None):
         """x [B,H,W,C0] (++ skip [B,H,W,C1] on channels); emb_silu = SiLU(time embedding) [B, emb_channels].
         emb_out: optional pre-computed `emb_layers[1].weight @ emb_silu` WITHOUT its bias (UNet-level batched GEMM,
-        see UNetModel2D_Next.precompute_emb); the bias then rides in the conv's bias vector."""
+        see UNetModel2D_Next.precompute_emb); the bias then rides in the conv's bias vector.
+        emb_bias: [Cout] fp16 = conv bias + emb_layers bias + emb_layers weight @ SiLU(emb) for ONE timestep shared by the whole
+        batch (UNetModel2D_Next.precompute_emb_table: the sampler computes it for all steps once per sample() call); the
+        embedding then needs no row vector in the conv epilogue at all."""
         B, H, W, _ = x.shape
         bias1 = None
-        if emb_out is None:
+        if emb_bias is not None:
+            emb_out, bias1 = None, emb_bias
+        elif emb_out is None:
             emb_out = self.emb_layers[1](emb_silu)
         else:
             conv, lin = self.in_layers[2], self.emb_layers[1]
@@ -160,7 +167,7 @@ class ResBlock(TimestepBlock, PackCache):
         # normalises in place (the raw conv output is consumed by this norm only); else the conv emits the statistics
         n2 = self.out_layers[0]
         g2, b2 = n2._w()
-        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W, bias=bias1, want_stats=True,
+        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W if emb_out is not None else 0, bias=bias1, want_stats=True,
                               gn=(g2, b2, n2.num_groups, n2.eps, True))
         if not getattr(h, "_vd_normalized", False):
             h = n2(h, silu=True)
@@ -326,6 +333,25 @@ class UNetModel2D_Next(nn.Module, PackCache):
             for j, (i, _) in enumerate(lst):
                 out[i] = o[j]
         return out
+
+    def precompute_emb_table(self, emb_silu_steps):
+        """emb_silu_steps [S, E] = SiLU(time embedding) of S timesteps -> (fp16 [S, total], {data block index: (offset, Cout)}):
+        per timestep and ResBlock the COMPLETE bias vector of the block's first conv (conv bias + emb_layers bias +
+        emb_layers weight @ emb; reference openaimodel.py:263-266 adds emb_out to h behind the conv).  Everything here depends
+        on t only, so a sampler whose batch shares one timestep per step computes it once for all steps (three batched GEMMs
+        with M = S) and the step graph carries no time-embedding launches.  None for nets without ResBlocks (0-D flow)."""
+        res = [(i, blk[0]) for i, blk in enumerate(self.data_blocks) if isinstance(blk[0], ResBlock)]
+        if not res:
+            return None
+        outs = self.precompute_emb(emb_silu_steps)
+        cols, layout, off = [], {}, 0
+        for i, rb in res:
+            conv, lin = rb.in_layers[2], rb.emb_layers[1]
+            b = conv.bias.detach().float() + lin.bias.detach().float()
+            cols.append((outs[i].float() + b[None, :]).to(torch.float16))
+            layout[i] = (off, rb.out_channels)
+            off += rb.out_channels
+        return torch.cat(cols, dim=1).contiguous(), layout
 
     def get_d_head_n_heads(self, ch):
         if self.num_head_channels is None:

@@ -35,7 +35,7 @@ class String_Reg_Buffer(nn.Module):
         return bytes(self.output_string.tolist()).decode()
 
 
-def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1):
+def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1, emb_rows=None):
     """Walk i/m/o orders of `data_net` (reference vd.py:352-378 / 429-453).
 
     ctx_specs: list of (context_blocks, context [B, L, Dc], ratio, kv_cache or None), one per context type.
@@ -43,9 +43,15 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     repeat > 1: the batch the reference would feed is `x` replicated `repeat` times ([x; x] of classifier-free guidance,
     ddim.py:144-149) with identical timesteps per replica, while contexts / emb carry the full repeat * B rows.  The data
     blocks in front of the first context block see identical inputs in every replica, so they run once on B rows and the
-    result (and the skip tensors saved so far) is replicated where the contexts make the replicas diverge."""
+    result (and the skip tensors saved so far) is replicated where the contexts make the replicas diverge.
+    emb_rows: {data block index: [Cout] fp16} complete first-conv bias vectors of the ResBlocks for the ONE timestep the whole
+    batch shares (VD_v2_0.precompute_step_emb); emb_silu may then be None."""
     d_iter = iter(enumerate(data_net.data_blocks))
-    emb_outs = data_net.precompute_emb(emb_silu) if hasattr(data_net, "precompute_emb") else {}
+    if emb_rows is not None:
+        emb_outs = {}
+    else:
+        emb_rows = {}
+        emb_outs = data_net.precompute_emb(emb_silu) if hasattr(data_net, "precompute_emb") else {}
     c_iters = [iter(spec[0]) for spec in ctx_specs]
     ratios = np.array([float(spec[2]) for spec in ctx_specs], dtype=np.float64)
     ratios = ratios / ratios.sum()
@@ -85,9 +91,10 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
             di, blk = next(d_iter)
             eo = emb_outs.get(di)
             if shared:
-                h = blk(h, emb_silu[:nb], None, emb_out=None if eo is None else eo[:nb])
+                h = blk(h, None if emb_silu is None else emb_silu[:nb], None, emb_out=None if eo is None else eo[:nb],
+                        emb_bias=emb_rows.get(di))
             else:
-                h = blk(h, emb_silu, None, emb_out=eo)
+                h = blk(h, emb_silu, None, emb_out=eo, emb_bias=emb_rows.get(di))
         elif ltype == "c":
             if shared:  # the replicas diverge here
                 rep = lambda t: ops.repeat_batch(t, repeat)   # per-channel statistics of the tensors travel along
@@ -102,7 +109,7 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
             skip = hs.pop()
         elif ltype == "d":
             di, blk = next(d_iter)
-            h = blk(h, emb_silu, None, skip=skip, emb_out=emb_outs.get(di))
+            h = blk(h, emb_silu, None, skip=skip, emb_out=emb_outs.get(di), emb_bias=emb_rows.get(di))
             skip = None
         elif ltype == "c":
             h = run_context(h)
@@ -236,6 +243,19 @@ class VD_v2_0(nn.Module):
         net = self.diffuser[glayer_ptr]
         return net.time_embed.forward_silu(timestep_embedding(timesteps, net.model_channels))
 
+    @torch.no_grad()
+    def precompute_step_emb(self, x_type, timesteps, multicontext=False):
+        """Everything of the UNet forward that depends on t alone -- timestep_embedding -> time_embed MLP -> SiLU -> every
+        ResBlock's emb_layers projection (reference vd.py:339-349, openaimodel.py:2627-2633, :263) -- for ALL `timesteps` [S]
+        at once: (fp16 [S, total], layout) of UNetModel2D_Next.precompute_emb_table, or None when the data flow has no such
+        table (0-D text-latent flow).  A caller whose batch shares one timestep per step hands row i to apply_model* as
+        x_info['emb_rows'] (DDIMSampler does, through a static buffer the step graph reads)."""
+        net = self.diffuser[x_type]
+        if not hasattr(net, "precompute_emb_table"):
+            return None
+        glayer_ptr = x_type if (multicontext or self.global_layer_ptr is None) else self.global_layer_ptr
+        return net.precompute_emb_table(self._emb_silu(glayer_ptr, timesteps))
+
     @staticmethod
     def _prep(x):
         if not x.is_cuda:
@@ -247,17 +267,21 @@ class VD_v2_0(nn.Module):
         x_type, x = x_info["type"], x_info["x"]
         c_type, c = c_info["type"], c_info["c"]
         glayer_ptr = x_type if self.global_layer_ptr is None else self.global_layer_ptr
-        emb = self._emb_silu(glayer_ptr, timesteps)
+        rows = x_info.get("emb_rows")   # extension key: the t-only part precomputed for a batch that shares its timestep
+        emb = self._emb_silu(glayer_ptr, timesteps) if rows is None else None
         spec = (self.diffuser[c_type].context_blocks, self._prep(c), 1.0, c_info.get("kv_cache"))
-        return run_unet(self.diffuser[x_type], [spec], self._prep(x), emb, repeat=int(x_info.get("repeat", 1))).to(x.dtype)
+        return run_unet(self.diffuser[x_type], [spec], self._prep(x), emb, repeat=int(x_info.get("repeat", 1)),
+                        emb_rows=rows).to(x.dtype)
 
     @torch.no_grad()
     def apply_model_multicontext(self, x_info, timesteps, c_info_list, mixing_type="attention"):
         """c_info_list: [{type, c, ratio}, ...]; 'attention' mixing = ratio-weighted sum of the context blocks."""
         x_type, x = x_info["type"], x_info["x"]
         assert mixing_type in ("attention", "layer")
-        emb = self._emb_silu(x_type, timesteps)  # reference takes time_embed from diffuser[x_type] here (vd.py:415-417)
+        rows = x_info.get("emb_rows")
+        # reference takes time_embed from diffuser[x_type] here (vd.py:415-417)
+        emb = self._emb_silu(x_type, timesteps) if rows is None else None
         specs = [(self.diffuser[ci["type"]].context_blocks, self._prep(ci["c"]), ci["ratio"], ci.get("kv_cache"))
                  for ci in c_info_list]
         return run_unet(self.diffuser[x_type], specs, self._prep(x), emb, mixing_type,
-                        repeat=int(x_info.get("repeat", 1))).to(x.dtype)
+                        repeat=int(x_info.get("repeat", 1)), emb_rows=rows).to(x.dtype)
