@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 5
+#define VD_HIP_ABI_VERSION 6
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -48,6 +48,9 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
 #define VD_EPI_LN_INLOOP 64   /* with VD_EPI_LNFOLD and ln_stats == NULL: row statistics inside the K loop (explicit opt-in) */
 #define VD_EPI_GROUPNORM 128  /* out = [SiLU](GroupNorm(epilogue result)): see VdGemmDesc.gn_gamma; split launches only   */
 #define VD_EPI_GN_SILU 256    /* ... followed by SiLU                                                                      */
+#define VD_EPI_LN_SUMS 512    /* with VD_EPI_LNFOLD (ABI 6): ln_stats holds (sum, sum of squares) of every A row -- what a producer
+                               * launch accumulated through VdGemmDesc.row_sums -- instead of (mean, rstd); the epilogue derives
+                               * mean / rstd over K with ln_eps */
 
 #define VD_ACT_NONE 0
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
@@ -121,6 +124,13 @@ typedef struct VdGemmDesc {
     const void* skip_a1;
     const void* skip_w;
     int32_t skip_c0, skip_c1, skip_lda0, skip_lda1, skip_ldw, reserved4;
+    /* Row statistics for a consuming LayerNorm fold (ABI 6): fp32 [M][2], ZEROED by the caller; every block adds (atomically)
+     * the sum and the sum of squares of the fp16 values it stores over its columns of each row, so after the launch
+     * row_sums[m] = (sum_n out[m][n], sum_n out[m][n]^2) -- the statistics half of the nn.LayerNorm in front of the NEXT
+     * projection (lib/model_zoo/attention.py:214-218) without vd_row_stats_f16's launch and extra read.  The consumer passes the
+     * buffer as ln_stats with VD_EPI_LN_SUMS.  Only unsplit gemm_f16_kernel launches with vector-aligned fp16 output take it:
+     * ask vd_gemm_row_sums_ok(desc) first. */
+    float* row_sums;
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -131,6 +141,8 @@ typedef struct VdGemmDesc {
  *   HF CLIP linear layers reached from lib/model_zoo/clip.py:58-61,95-100 */
 int vd_gemm_f16(const VdGemmDesc* desc, hipStream_t stream);
 size_t vd_gemm_workspace_bytes(const VdGemmDesc* desc);
+/* 1 when the launch vd_gemm_f16 would plan for `desc` can accumulate VdGemmDesc.row_sums (see there), else 0. */
+int vd_gemm_row_sums_ok(const VdGemmDesc* desc);
 /* Dry run of the launch planner: tile_cfg indexes the instantiation table of vd_gemm_config_name(); nsplit = split-K
  * factor.  Lets bench.py attribute measured time / algorithmic FLOPs to the kernel instantiation that actually ran. */
 int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);

@@ -221,6 +221,43 @@ def test_gemm_layernorm_fold(ops, dev, M, K, N, offset, inloop, monkeypatch):
     assert rel_l2(out, ref - b.float() - res.float()) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K,res,conv", [(8192, 640, 640, True, False), (2048, 1280, 1280, True, False), (512, 1280, 1280, False, True),
+                                           (8192 + 24, 640, 640, False, False), (2048, 1280, 320, True, False)])
+def test_gemm_row_sums_feed_the_layernorm_fold(ops, dev, M, N, K, res, conv):
+    """VdGemmDesc.row_sums (ABI 6): the epilogue of the launch that STORES x accumulates (sum, sum of squares) of every row of x;
+    the LayerNorm-folded consumer reads them with VD_EPI_LN_SUMS instead of running vd_row_stats_f16.  Checked: the sums
+    against torch on the stored fp16 values, and LayerNorm(x) @ W2^T through both statistics sources against torch fp32."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    a = rnd((M, K), dev, 1.0, 300)
+    w1 = rnd((N, K), dev, 0.04, 301)
+    b1 = rnd((N,), dev, 0.3, 302)
+    r = rnd((M, N), dev, 1.0, 303) + 0.7 if res else None
+    sums = ops.rowsum_take(M, a.device)
+    if conv and M % 64 == 0:   # proj_in: a 1x1 convolution on an 8x8 grid
+        x4 = ops.conv2d_nhwc(a.view(M // 64, 8, 8, K), w1, b1, ksize=1, stride=1, pad=0, row_sums=sums)
+        got = getattr(x4, "_vd_rowsums", None)
+        x = x4.view(M, N)
+    else:
+        x = ops.gemm(a, w1, bias=b1, res=r, row_sums=sums)
+        got = getattr(x, "_vd_rowsums", None)
+    assert got is not None, "the planned launch did not take row_sums"
+    xf = x.float()
+    ref_s = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1)
+    assert rel_l2(got[:, 0], ref_s[:, 0]) < 1e-4 and rel_l2(got[:, 1], ref_s[:, 1]) < 1e-5
+    N2 = 1920
+    w2 = rnd((N2, N), dev, 0.05, 304)
+    ln = torch.nn.LayerNorm(N, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(305)).to(dev))
+        ln.bias.copy_(0.2 * torch.randn(N, generator=torch.Generator().manual_seed(306)).to(dev))
+    ref = F.layer_norm(xf, (N,), ln.weight.float(), ln.bias.float(), 1e-5) @ w2.float().t()
+    wp, bp, cs = fold_layernorm(w2, None, ln)
+    y_sums = ops.gemm(x, wp, bias=bp, colsum=cs, ln_eps=1e-5, ln_sums=got)
+    y_stat = ops.gemm(x, wp, bias=bp, colsum=cs, ln_eps=1e-5)
+    assert rel_l2(y_sums, ref) < 3e-3 and rel_l2(y_stat, ref) < 3e-3
+    assert rel_l2(y_sums, y_stat) < 1e-3
+
+
 @pytest.mark.parametrize("M,C", [(1024, 320), (4096 + 40, 320)])
 def test_gemm_layernorm_fold_geglu(ops, dev, M, C):
     from lib.model_zoo.hip_layers import fold_layernorm

@@ -39,6 +39,7 @@ struct AttnArgs {
     int causal;
     int nqb, BH;
     int ctx_map;   // block -> (batch, head, query block) mapping for short contexts, see the kernel
+    int pair_contig;   // long K / V: an XCD owns consecutive (batch, head) pairs (else pairs xcd, xcd + 8, ...)
 };
 
 // NWV waves per block (4, or 8 for long self-attention: the K / V tile's LDS-DMA requests are shared by twice the queries, and
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
             bh = (grp / p.nqb) * p.H + idx % p.H;
             qb = grp % p.nqb;
         } else if ((p.BH & 7) == 0) {
+            // an XCD owns BH / 8 CONSECUTIVE (batch, head) pairs (round 5; before: pairs xcd, xcd + 8, ... = one head of every
+            // sample): the heads of a token are neighbours in memory (D * 2 = 80 .. 320 bytes each inside the fused q|k|v row),
+            // so consecutive pairs share the 128-byte lines of K / V / q / out inside ONE L2 instead of pulling every line into
+            // two of them (counter traffic of the D = 40 launch: 2.1x the unique bytes).  VD_ATTN_PAIRMAP=0: the old interleave.
             const int xcd = bid & 7, idx = bid >> 3;
-            bh = xcd + 8 * (idx / p.nqb);
+            bh = p.pair_contig ? xcd * (p.BH >> 3) + idx / p.nqb : xcd + 8 * (idx / p.nqb);
             qb = idx % p.nqb;
         } else {
             bh = bid / p.nqb;
@@ -596,6 +601,8 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     a.BH = B * H;
     static const char* ctx_env = getenv("VD_ATTN_CTXMAP");   // development switch: 0 = always the K/V-locality mapping
     a.ctx_map = (Nk <= 2 * KV && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
+    static const char* pm_env = getenv("VD_ATTN_PAIRMAP");   // development switch: 0 = pairs interleaved over the XCDs (rounds 1-4)
+    a.pair_contig = (pm_env && pm_env[0] == '0') ? 0 : 1;
     static const char* w8_env = getenv("VD_ATTN_W8");        // development switch: 0 = always 4 waves per block
     const bool w8 = !(w8_env && w8_env[0] == '0') && causal == 0 && Nq >= 2048 && Nk >= 1024;
     if (H == 1 && (D == 128 || D == 256 || D == 512)) {   // one wide head: head dim split over the waves of a block

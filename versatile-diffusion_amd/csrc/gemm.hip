@@ -789,6 +789,30 @@ extern "C" int vd_gemm_groupnorm_ok(const VdGemmDesc* dp, int conv3x3_wstream) {
     return (conv3x3_wstream || n > 1) ? 1 : 0;   // the weight-streaming conv always runs split + reduce
 }
 
+// launches whose part 2 can accumulate VdGemmDesc.row_sums: an unsplit gemm_f16_kernel (not the halo conv, not a reduce kernel)
+// with the fast write-out path (vector-aligned fp16 output, residual OR row vector) and a power-of-two number of 16-byte
+// segments per tile row
+static bool row_sums_ok(const GemmArgs& a, int cfg, int nsplit) {
+    const VdGemmDesc& d = a.d;
+    if (cfg >= T_COUNT || nsplit > 1 || d.act == VD_ACT_GEGLU) return false;
+    if (d.flags & (VD_EPI_OUT_F32 | VD_EPI_GROUPNORM | VD_EPI_BIAS_ALONG_M)) return false;
+    if ((d.flags & VD_EPI_RESIDUAL) && (d.flags & VD_EPI_ROWVEC)) return false;
+    if ((d.N & 7) || (d.ldc & 7) || (d.ldr & 7)) return false;
+    const int ch = kCfg[cfg].bn / 8;
+    if ((ch & (ch - 1)) != 0 || ch > 64) return false;
+    // two-pass epilogues (256 x 320) and the one-wave-per-SIMD development tiles keep the plain path
+    return cfg == T128x128 || cfg == T128x64 || cfg == T64x64 || cfg == T128x128w8 || cfg == T128x64w8 || cfg == T128x128d ||
+           cfg == T128x64d || cfg == T64x64d || cfg == T128x256 || cfg == T256x128;
+}
+
+extern "C" int vd_gemm_row_sums_ok(const VdGemmDesc* dp) {
+    if (dp == nullptr) return 0;
+    GemmArgs a;
+    int c = 0, n = 1;
+    if (plan_gemm(dp, a, c, n) != VD_OK) return 0;
+    return row_sums_ok(a, c, n) ? 1 : 0;
+}
+
 extern "C" int vd_gemm_plan(const VdGemmDesc* dp, int* tile_cfg, int* nsplit) {
     GemmArgs a;
     int c = 0, n = 1;
@@ -848,6 +872,11 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         return VD_ERR_UNSUPPORTED;
     }
     VD_REQUIRE(((size_t)d.out_stats & 7) == 0, "vd_gemm_f16: out_stats must be 8-byte aligned");
+    if (d.row_sums != nullptr && !row_sums_ok(a, cfg, nsplit)) {
+        vd_set_error("vd_gemm_f16: row_sums requested but the planned launch cannot accumulate them (vd_gemm_row_sums_ok)");
+        return VD_ERR_UNSUPPORTED;
+    }
+    if (d.flags & VD_EPI_LN_SUMS) VD_REQUIRE((d.flags & VD_EPI_LNFOLD) && d.ln_stats != nullptr, "vd_gemm_f16: VD_EPI_LN_SUMS needs VD_EPI_LNFOLD and ln_stats");
     if (d.flags & VD_EPI_GROUPNORM) {
         RnArgs rn;
         int nt = 0;

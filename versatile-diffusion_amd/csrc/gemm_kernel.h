@@ -101,6 +101,7 @@ struct EpiCtx {
     const f16* rowvec;
     const f16* res;
     void* out;
+    float* row_sums;   // VdGemmDesc.row_sums (gemm_f16_kernel's part 2 only), else null
     int N, ldc, ldr, rows_per_batch, flags, act;
     float alpha;
 };
@@ -114,6 +115,8 @@ __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
         e.out = reinterpret_cast<float*>(d.out) + (size_t)z * d.stride_out;
     else
         e.out = reinterpret_cast<f16*>(d.out) + (size_t)z * d.stride_out;
+    e.row_sums = d.row_sums + (size_t)z * d.M * 2;
+    if (d.row_sums == nullptr) e.row_sums = nullptr;
     e.N = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
     e.ldc = d.ldc;
     e.ldr = d.ldr;
@@ -396,6 +399,47 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                 }
             }
         };
+        // VdGemmDesc.row_sums: (sum, sum of squares) of the STORED values of each row over this block's columns, folded over the
+        // CH (a power of two <= 64: the host asked vd_gemm_row_sums_ok) consecutive lanes that share the row, one pair of
+        // atomic adds per row and block.  Its own loop (never taken by launches without the pointer: the usual path above keeps
+        // its instruction footprint).
+        if (e.row_sums != nullptr && (CH & (CH - 1)) == 0 && CH <= 64) {
+#pragma unroll
+            for (int k = 0; k < MAX_CH; ++k) {
+                const int c = tid + k * NT;
+                const int r = c / CH, cc = (c % CH) * 8;
+                const int row = m0 + (r / SEG) * WM + row0 + (r % SEG), col = out_n0 + cc;
+                const bool ok = c < ROWS * CH && row < M && col < e.N;
+                float s1 = 0.f, s2 = 0.f;
+                U4H8 o;
+                if (ok) {
+                    U4H8 t, a;
+                    t.u = *reinterpret_cast<const uint4*>(cs + r * CS_LD + cc);
+                    a.u = pre[k];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        o.e[i] = (f16)((float)t.e[i] + (float)a.e[i] + 0.f);
+                        const float v = (float)o.e[i];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                    f16* dst = reinterpret_cast<f16*>(e.out) + (size_t)row * e.ldc + col;
+                    if (nt) vd_store16_nt(dst, o.u);
+                    else *reinterpret_cast<uint4*>(dst) = o.u;
+                    if (keep) *reinterpret_cast<uint4*>(cs + r * CS_LD + cc) = o.u;
+                }
+#pragma unroll
+                for (int sh = 1; sh < CH; sh <<= 1) {
+                    s1 += __shfl_xor(s1, sh, 64);
+                    s2 += __shfl_xor(s2, sh, 64);
+                }
+                if (ok && (c % CH) == 0) {
+                    atomicAdd(e.row_sums + (size_t)row * 2, s1);
+                    atomicAdd(e.row_sums + (size_t)row * 2 + 1, s2);
+                }
+            }
+            return;
+        }
         if (nt) {
             if (keep) fast(std::true_type{}, std::true_type{});
             else fast(std::true_type{}, std::false_type{});
@@ -1090,8 +1134,17 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 ln_nmr = -mean * ln_rstd;
             } else {
                 const float2 st = lnst_r[i];
-                ln_rstd = st.y;
-                ln_nmr = -st.x * st.y;
+                if (d.flags & VD_EPI_LN_SUMS) {   // (sum, sum of squares) from the producer's row_sums
+                    const float inv_k = 1.0f / (float)d.K;
+                    const float mean = st.x * inv_k;
+                    float var = st.y * inv_k - mean * mean;
+                    if (var < 0.f) var = 0.f;
+                    ln_rstd = rsqrtf(var + d.ln_eps);
+                    ln_nmr = -mean * ln_rstd;
+                } else {
+                    ln_rstd = st.y;
+                    ln_nmr = -st.x * st.y;
+                }
             }
         }
         if (geglu) {

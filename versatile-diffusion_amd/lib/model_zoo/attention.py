@@ -22,16 +22,16 @@ class GEGLU(nn.Module, PackCache):
         super().__init__()
         self.proj = Linear(dim_in, dim_out * 2)
 
-    def forward(self, x, ln=None):
+    def forward(self, x, ln=None, ln_sums=None):
         """ln: the nn.LayerNorm the reference applies in front (x is then the UN-normalised input; folded, see
-        hip_layers.fold_layernorm)."""
+        hip_layers.fold_layernorm).  ln_sums: (sum, sum of squares) per row of x from the launch that stored x."""
         if ln is None:
             wp, bp = self._packed("geglu", (self.proj.weight, self.proj.bias),
                                   lambda: pack.pack_geglu(_h(self.proj.weight), _h(self.proj.bias)))
             return ops.linear(x, wp, bp, act=ops.ACT_GEGLU)
 
         wp, bp, cs = self.folded(ln)
-        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=cs, ln_eps=ln.eps)
+        return ops.linear(x, wp, bp, act=ops.ACT_GEGLU, colsum=cs, ln_eps=ln.eps, ln_sums=ln_sums)
 
     def folded(self, ln):
         """(gamma-folded GEGLU-packed weight, beta-folded packed bias, fp32 row sums of the packed weight), cached."""
@@ -50,8 +50,8 @@ class FeedForward(nn.Module):
         dim_out = dim if dim_out is None else dim_out
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), Linear(inner, dim_out))
 
-    def forward(self, x, res=None, ln=None):
-        """ln: the LayerNorm in front (folded).  Where the library has the one-launch kernel for this width (C = 320: the
+    def forward(self, x, res=None, ln=None, ln_sums=None):
+        """ln: the LayerNorm in front (folded); ln_sums: row statistics of x from its producer (ops.gemm(row_sums=...)).  Where the library has the one-launch kernel for this width (C = 320: the
         64x64 level, whose [M, 4C] GEGLU intermediate is 84 MB) LayerNorm, both projections, the gating and the residual
         run in vd_ff_geglu_f16; elsewhere GEGLU GEMM -> output GEMM."""
         C = x.shape[-1]
@@ -61,7 +61,7 @@ class FeedForward(nn.Module):
             wp, bp, _ = self.net[0].folded(ln)
             w2, b2 = out._w()
             return ops.ff_geglu(x, wp, bp, w2, b2, res, ln.eps)
-        return out(self.net[0](x, ln=ln), res=res)
+        return out(self.net[0](x, ln=ln, ln_sums=ln_sums), res=res)
 
 
 class CrossAttention(nn.Module, PackCache):
@@ -100,8 +100,10 @@ class CrossAttention(nn.Module, PackCache):
         return self._packed("q_ln", (self.to_q.weight, ln.weight, ln.bias),
                             lambda: fold_layernorm(_h(self.to_q.weight), None, ln))
 
-    def forward(self, x, context=None, res=None, kv=None, ln=None, qkv=None):
-        """x [B, N, C] -> to_out(attn) (+ res fused).  ln: the LayerNorm in front of the block's q (and self k / v)
+    def forward(self, x, context=None, res=None, kv=None, ln=None, qkv=None, ln_sums=None, out_sums=None):
+        """ln_sums: row statistics of x for `ln` (from x's producer); out_sums: zeroed fp32 [rows, 2] the output projection
+        accumulates the row statistics of ITS output into (for the LayerNorm in front of the next block part).
+        x [B, N, C] -> to_out(attn) (+ res fused).  ln: the LayerNorm in front of the block's q (and self k / v)
         projections, folded into them -- x is then the un-normalised input.  qkv: the fused self-attention projection when
         the caller has already computed it (SpatialTransformer's chained entry kernel)."""
         c = self.inner
@@ -112,7 +114,7 @@ class CrossAttention(nn.Module, PackCache):
                 qkv = ops.linear(x, self._w_qkv())
             else:
                 w, b, cs = self._w_qkv_ln(ln)
-                qkv = ops.linear(x, w, b, colsum=cs, ln_eps=ln.eps)
+                qkv = ops.linear(x, w, b, colsum=cs, ln_eps=ln.eps, ln_sums=ln_sums)
             a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, scale=self.scale)
         else:
             if kv is None:
@@ -121,14 +123,14 @@ class CrossAttention(nn.Module, PackCache):
                 # LayerNorm + to_q + attention over the (short) context in ONE launch: q never exists in memory
                 w, b, cs = self._w_q_ln(ln)
                 a = ops.xattn(x, w, b, cs, ln.eps, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
-                return self.to_out[0](a, res=res)
+                return self.to_out[0](a, res=res, row_sums=out_sums)
             if ln is None:
                 q = self.to_q(x)
             else:
                 w, b, cs = self._w_q_ln(ln)
                 q = ops.linear(x, w, b, colsum=cs, ln_eps=ln.eps)
             a = ops.attention(q, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
-        return self.to_out[0](a, res=res)
+        return self.to_out[0](a, res=res, row_sums=out_sums)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -144,11 +146,15 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
 
-    def forward(self, x, context=None, kv=None, qkv=None):
+    def forward(self, x, context=None, kv=None, qkv=None, ln1_sums=None):
         if hip_layers.LN_FOLD:  # the three LayerNorms ride in the q/k/v, q and GEGLU projections (VD_EPI_LNFOLD)
-            x = self.attn1(x, res=x, ln=self.norm1, qkv=qkv)
-            x = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2)
-            return self.ff(x, res=x, ln=self.norm3)
+            x = self.attn1(x, res=x, ln=self.norm1, qkv=qkv, ln_sums=ln1_sums)
+            # norm3's statistics: accumulated by attn2's output projection where the feed-forward runs as separate GEMMs (the
+            # one-launch feed-forward of the 64x64 level normalises in registers)
+            C = x.shape[-1]
+            s3 = None if ops.ff_geglu_supported(C) else ops.rowsum_take(x.numel() // C, x.device)
+            x = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2, out_sums=s3)
+            return self.ff(x, res=x, ln=self.norm3, ln_sums=getattr(x, "_vd_rowsums", None))
         x = self.attn1(self.norm1(x), res=x)
         x = self.attn2(self.norm2(x), context=context, res=x, kv=kv)
         x = self.ff(self.norm3(x), res=x)
@@ -191,6 +197,8 @@ class SpatialTransformer(nn.Module):
             h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps)
             h = blk(h, context=context, kv=kv, qkv=qkv)
             return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)
-        h = self.proj_in(self.norm(x, silu=False))
-        h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv)
+        # norm1's row statistics ride on proj_in's epilogue (ops.gemm(row_sums=...)) instead of a vd_row_stats_f16 launch
+        s1 = ops.rowsum_take(B * H * W, x.device) if hip_layers.LN_FOLD else None
+        h = self.proj_in(self.norm(x, silu=False), row_sums=s1)
+        h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv, ln1_sums=getattr(h, "_vd_rowsums", None))
         return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)

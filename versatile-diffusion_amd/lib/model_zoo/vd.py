@@ -86,6 +86,18 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     h = x
     nb = x.shape[0]
     shared = repeat > 1
+    # LayerNorm row statistics accumulated by producer epilogues live in one arena per forward, zeroed by ONE fill
+    arena = data_net.__dict__.get("_vd_rowsum_arena")
+    if arena is None:
+        arena = data_net.__dict__["_vd_rowsum_arena"] = ops.RowSumArena()
+    arena.begin(x.device)
+    try:
+        return _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs)
+    finally:
+        arena.end()
+
+
+def _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs):
     for ltype in data_net.i_order + data_net.m_order:
         if ltype == "d":
             di, blk = next(d_iter)

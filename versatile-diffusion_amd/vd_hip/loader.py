@@ -32,6 +32,7 @@ class VdGemmDesc(ctypes.Structure):
         ("skip_a0", ctypes.c_void_p), ("skip_a1", ctypes.c_void_p), ("skip_w", ctypes.c_void_p),
         ("skip_c0", ctypes.c_int32), ("skip_c1", ctypes.c_int32), ("skip_lda0", ctypes.c_int32), ("skip_lda1", ctypes.c_int32),
         ("skip_ldw", ctypes.c_int32), ("reserved4", ctypes.c_int32),
+        ("row_sums", ctypes.c_void_p),
     ]
 
 
@@ -45,6 +46,7 @@ PROTOTYPES = {
     "vd_gemm_stat_rows": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_groupnorm_ok": (_I, [ctypes.POINTER(VdGemmDesc), _I]),
     "vd_gemm_skip_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
+    "vd_gemm_row_sums_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_gemm_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),

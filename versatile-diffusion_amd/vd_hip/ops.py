@@ -7,13 +7,14 @@ No arithmetic is done in torch here.
 import ctypes
 import functools
 import os
+import threading
 
 import torch
 
 from .loader import VdGemmDesc, VdHipError, lib
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD, EPI_LN_INLOOP = 1, 2, 4, 8, 16, 32, 64
-EPI_GROUPNORM, EPI_GN_SILU = 128, 256
+EPI_GROUPNORM, EPI_GN_SILU, EPI_LN_SUMS = 128, 256, 512
 ACT_NONE, ACT_GEGLU, ACT_QUICK_GELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 _ws_cache = {}
@@ -166,7 +167,7 @@ def repeat_batch(t, repeat):
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
-         want_stats=False, stat_img_rows=0, w_stream=None, gn=None, skip=None):
+         want_stats=False, stat_img_rows=0, w_stream=None, gn=None, skip=None, row_sums=None, ln_sums=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -186,9 +187,17 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     skip = (s0, s1 or None, w_skip [N, C_s0 + C_s1]): a 1x1 convolution of cat(s0, s1) on the output grid folded into this 3x3
     convolution as extra K (ResBlock's skip_connection(x) + h; its bias belongs into `bias`).  Returns None WITHOUT launching
     when the planned launch cannot take it (vd_gemm_skip_ok): the caller then runs the 1x1 convolution itself.
+    row_sums: zeroed fp32 [M, 2] (rowsum_take): the epilogue adds (sum, sum of squares) of every stored row -- the statistics of
+    the LayerNorm folded into the NEXT projection; comes back as `out._vd_rowsums` when the planned launch can accumulate them
+    (vd_gemm_row_sums_ok), else the attribute is absent and the consumer runs vd_row_stats_f16.
+    ln_sums: with colsum, such a buffer describing the rows of a0 (VD_EPI_LN_SUMS) instead of the row_stats launch.
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
-    _req(colsum, "colsum", torch.float32)
+    _req(colsum, "colsum", torch.float32); _req(row_sums, "row_sums", torch.float32); _req(ln_sums, "ln_sums", torch.float32)
+    if out is not None:   # a re-used output tensor must not keep the statistics of what it held before
+        for attr in ("_vd_stats", "_vd_normalized", "_vd_rowsums"):
+            if hasattr(out, attr):
+                delattr(out, attr)
     # (the plain N = 320 projections measure equal on both kernels -- 24.9 vs 24.2 us: with one 128-row block per CU in
     # lock-step a launch is its load / store phases either way; the LayerNorm-folded q | k | v projection is 59 vs 66 us + the
     # statistics launch)
@@ -239,7 +248,12 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             raise VdHipError("gemm: the LayerNorm fold takes a plain single-source, unbatched A")
         flags |= EPI_LNFOLD
         d.colsum, d.ln_eps = colsum.data_ptr(), float(ln_eps)
-        if not LN_INLOOP:   # two-pass statistics from their own launch instead of the K loop's running sums
+        if ln_sums is not None and LN_SUMS:   # (sum, sum of squares) of the rows of a0, accumulated by the launch that stored a0
+            if ln_sums.numel() != 2 * int(M):
+                raise VdHipError("gemm: ln_sums does not describe the %d rows of a0" % int(M))
+            flags |= EPI_LN_SUMS
+            d.ln_stats = ln_sums.data_ptr()
+        elif not LN_INLOOP:   # two-pass statistics from their own launch instead of the K loop's running sums
             ln_stats = row_stats(a0, int(K), int(M), float(ln_eps), ldx=int(lda0) if lda0 else int(K))
             d.ln_stats = ln_stats.data_ptr()
         else:
@@ -385,6 +399,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             sbuf = torch.empty((int(M) // rows.value, n_out, 2), dtype=torch.float32, device=a0.device)
             d.out_stats = sbuf.data_ptr()
             stats = ChanStats(sbuf, hw // rows.value, n_out, hw)
+    rs_on = False
+    if row_sums is not None and LN_SUMS and max(batch, 1) == 1 and row_sums.numel() == 2 * int(M):
+        if lib().vd_gemm_row_sums_ok(ctypes.byref(d)):
+            d.row_sums = row_sums.data_ptr()
+            rs_on = True
     if _prof is not None:
         _check(lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(plan_cfg), ctypes.byref(plan_ns)))
         name = gemm_kernel_name(plan_cfg.value)
@@ -405,7 +424,51 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         out._vd_stats = stats
     if fused_gn:
         out._vd_normalized = True
+    if rs_on:
+        out._vd_rowsums = row_sums
     return out
+
+
+# LayerNorm row statistics from the producer (round 5): the GEMM that STORES the rows a folded LayerNorm will normalise adds
+# (sum, sum of squares) per row into a zeroed fp32 [rows, 2] buffer (VdGemmDesc.row_sums), the consumer reads it with
+# VD_EPI_LN_SUMS -- the 22 vd_row_stats_f16 launches of a UNet forward (and their extra read of x) disappear.  The buffers of
+# one forward are slices of ONE arena zeroed by one fill (RowSumArena, begun by vd.run_unet); VD_LN_SUMS=0: row_stats launches.
+LN_SUMS = os.environ.get("VD_LN_SUMS", "1") != "0"
+_tls = threading.local()
+
+
+class RowSumArena(object):
+    """Bump allocator over one zeroed fp32 [need, 2] tensor per forward; `need` is what the previous forward of this owner
+    took (the first forward, and any request beyond it, falls back to a torch.zeros of its own)."""
+
+    def __init__(self):
+        self.need, self.used, self.buf = 0, 0, None
+
+    def begin(self, device):
+        self.used = 0
+        self.buf = torch.zeros((self.need, 2), dtype=torch.float32, device=device) if self.need > 0 else None
+        _tls.arena = self
+
+    def take(self, rows, device):
+        rows = int(rows)
+        start, self.used = self.used, self.used + rows
+        if self.buf is not None and self.used <= self.buf.shape[0] and self.buf.device == device:
+            return self.buf[start:start + rows]
+        return torch.zeros((rows, 2), dtype=torch.float32, device=device)
+
+    def end(self):
+        self.need, self.buf = self.used, None
+        _tls.arena = None
+
+
+def rowsum_take(rows, device):
+    """Zeroed fp32 [rows, 2] for VdGemmDesc.row_sums, or None when producer row statistics are switched off."""
+    if not LN_SUMS:
+        return None
+    arena = getattr(_tls, "arena", None)
+    if arena is not None:
+        return arena.take(rows, device)
+    return torch.zeros((int(rows), 2), dtype=torch.float32, device=device)
 
 
 SKIP_FOLD = os.environ.get("VD_SKIP_FOLD", "1") != "0"   # ResBlock skip 1x1 convolution as extra K of the second 3x3 conv
@@ -541,7 +604,12 @@ def linear(x, w, bias=None, **kw):
     act = kw.get("act", ACT_NONE)
     n_out = w.shape[0] // 2 if act == ACT_GEGLU else w.shape[0]
     out = gemm(x, w, bias=bias, M=x.numel() // x.shape[-1], **kw)
-    return out.view(*lead, n_out)
+    v = out.view(*lead, n_out)
+    for attr in ("_vd_stats", "_vd_rowsums"):   # a view does not carry the producer's statistics along: re-attach them
+        a = getattr(out, attr, None)
+        if a is not None:
+            setattr(v, attr, a)
+    return v
 
 
 def conv2d_nhwc(x, w_packed, bias=None, *, ksize=3, stride=1, pad=1, ups=0, x1=None, cout=None, pad_hi=None, **kw):
