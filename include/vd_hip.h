@@ -48,9 +48,9 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
 #define VD_EPI_LN_INLOOP 64   /* with VD_EPI_LNFOLD and ln_stats == NULL: row statistics inside the K loop (explicit opt-in) */
 #define VD_EPI_GROUPNORM 128  /* out = [SiLU](GroupNorm(epilogue result)): see VdGemmDesc.gn_gamma; split launches only   */
 #define VD_EPI_GN_SILU 256    /* ... followed by SiLU                                                                      */
-#define VD_EPI_LN_SUMS 512    /* with VD_EPI_LNFOLD (ABI 6): ln_stats holds (sum, sum of squares) of every A row -- what a producer
-                               * launch accumulated through VdGemmDesc.row_sums -- instead of (mean, rstd); the epilogue derives
-                               * mean / rstd over K with ln_eps */
+#define VD_EPI_LN_SUMS 512    /* with VD_EPI_LNFOLD (ABI 6): ln_stats points at the int64 [M][2] fixed-point (sum, sum of squares)
+                               * of every A row that a producer launch accumulated through VdGemmDesc.row_sums, instead of fp32
+                               * (mean, rstd); the epilogue derives mean / rstd over K with ln_eps */
 
 #define VD_ACT_NONE 0
 #define VD_ACT_GEGLU 1      /* out[:, j] = val_j * gelu_erf(gate_j); W/bias packed per 64 rows as [32 val | 32 gate] */
@@ -124,13 +124,14 @@ typedef struct VdGemmDesc {
     const void* skip_a1;
     const void* skip_w;
     int32_t skip_c0, skip_c1, skip_lda0, skip_lda1, skip_ldw, reserved4;
-    /* Row statistics for a consuming LayerNorm fold (ABI 6): fp32 [M][2], ZEROED by the caller; every block adds (atomically)
-     * the sum and the sum of squares of the fp16 values it stores over its columns of each row, so after the launch
+    /* Row statistics for a consuming LayerNorm fold (ABI 6): int64 [M][2], ZEROED by the caller; every block adds (atomically)
+     * the sum and the sum of squares of the fp16 values it stores over its columns of each row, in fixed point (sum x 2^24, sum
+     * of squares x 2^16: integer adds, so the result does not depend on the order the blocks arrive in), so after the launch
      * row_sums[m] = (sum_n out[m][n], sum_n out[m][n]^2) -- the statistics half of the nn.LayerNorm in front of the NEXT
      * projection (lib/model_zoo/attention.py:214-218) without vd_row_stats_f16's launch and extra read.  The consumer passes the
      * buffer as ln_stats with VD_EPI_LN_SUMS.  Only unsplit gemm_f16_kernel launches with vector-aligned fp16 output take it:
      * ask vd_gemm_row_sums_ok(desc) first. */
-    float* row_sums;
+    void* row_sums;
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -197,6 +198,12 @@ int vd_conv3x3_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStre
 int vd_gemm_wstream_supported(const VdGemmDesc* desc);
 int vd_gemm_wstream_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
 int vd_conv3x3_wstream_supported(const VdGemmDesc* desc);
+/* Split factors the two weight-streaming launchers will use for `desc` (ABI 6): set VdGemmDesc.split_k to *nsplit before sizing
+ * the workspace with vd_gemm_workspace_bytes.  vd_conv3x3_wstream_plan answers 0 when the launch goes to the whole-K kernel
+ * (conv_wsk_kernel.h, round 5: a block owns 128 pixels x 32 channels for the whole K, its four waves split the k-steps, the
+ * fused epilogue and the GroupNorm statistics run in the kernel): no workspace, no reduce launch. */
+int vd_conv3x3_wstream_plan(const VdGemmDesc* desc, int* nsplit);
+int vd_gemm_wstream_plan(const VdGemmDesc* desc, int* nsplit);
 /* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */
 int vd_conv3x3_wstream_set_variant(int variant, int target_blocks);
 /* The same weights-in-registers main loop for every 3x3 / stride 1 / pad 1 convolution (optional nearest-2x upsample in

@@ -243,7 +243,8 @@ def test_gemm_row_sums_feed_the_layernorm_fold(ops, dev, M, N, K, res, conv):
     assert got is not None, "the planned launch did not take row_sums"
     xf = x.float()
     ref_s = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1)
-    assert rel_l2(got[:, 0], ref_s[:, 0]) < 1e-4 and rel_l2(got[:, 1], ref_s[:, 1]) < 1e-5
+    assert got.dtype == torch.int64   # fixed point (sum x 2^24, sum of squares x 2^16): integer adds commute, runs are bit-identical
+    assert rel_l2(got[:, 0].double() / 2 ** 24, ref_s[:, 0]) < 1e-4 and rel_l2(got[:, 1].double() / 2 ** 16, ref_s[:, 1]) < 1e-5
     N2 = 1920
     w2 = rnd((N2, N), dev, 0.05, 304)
     ln = torch.nn.LayerNorm(N, eps=1e-5).to(dev)
@@ -1093,8 +1094,11 @@ def test_gemm_out_stats(ops, dev, case):
     (2, 128, 0, 256, False, False),       # one image pair, one column slice
     (4, 64, 64, 512, True, True),
     (6, 192, 0, 256, False, False),       # 3 chunks: ragged split
+    (2, 256, 0, 256, True, True),         # 4 chunks: the fewest the whole-K kernel takes
+    (4, 192, 128, 512, False, True),      # 5 chunks over two sources
+    (8, 2560, 0, 256, True, False),       # 40 chunks: the longest unrolled sequence
 ])
-def test_conv3x3_wstream(ops, dev, case):
+def test_conv3x3_wstream(ops, dev, case, monkeypatch):
     """vd_conv3x3_wstream_f16 (weights in MFMA-fragment order streamed into registers, halo in LDS, split over chunks +
     reduce) against torch's fp32 convolution and against the same problem on gemm_f16_kernel; every instance, several grid
     targets; statistics of the stored output."""
@@ -1118,6 +1122,20 @@ def test_conv3x3_wstream(ops, dev, case):
     wp, wsm = pack_conv_weight(wt), pack_conv_weight_stream(wt)
     old = ops.conv2d_nhwc(x, wp, b, **kw)
     assert rel_l2(old, ref) < 2e-3
+    # round 5: the whole-K kernel (conv_wsk_kernel.h: no split, epilogue + statistics in the kernel) wherever the input has at
+    # least 4 chunks (forced here for small grids too)
+    monkeypatch.setenv("VD_WSK", "1")
+    monkeypatch.setenv("VD_WSK_MIN_BLOCKS", "1")
+    outk = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
+    assert outk.shape == ref.shape and rel_l2(outk, ref) < 2e-3
+    stk = ops.stats_of(outk)
+    assert stk is not None and stk.T == 1 and stk.HW == 64
+    _stats_close(stk, _chan_stats_ref(outk.view(B, 64, Co), B, 1), 64)
+    if kw.get("rowvec") is not None:   # one row vector shared by the whole batch (rows_per_batch = M)
+        kw1 = dict(kw, rowvec=kw["rowvec"][:1].contiguous(), rows_per_batch=B * 64)
+        o1 = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw1)
+        assert rel_l2(o1, ref - kw["rowvec"].float().view(B, 1, 1, Co) + kw["rowvec"][:1].float().view(1, 1, 1, Co)) < 2e-3
+    monkeypatch.setenv("VD_WSK", "0")   # the split kernel + reduce launch
     try:
         for var in range(4):
             for target in (256, 64, 1024):

@@ -2,6 +2,7 @@
 // -amdgpu-mfma-vgpr-form: the 128 accumulator registers of a wave live in AGPRs, the architectural VGPRs hold the ring of
 // weight fragments in flight, the pixel fragments and the addresses.
 #include "conv_wstream_kernel.h"
+#include "conv_wsk_kernel.h"
 #include "conv_wreg_kernel.h"
 #include "gemm_wstream_kernel.h"
 
@@ -49,6 +50,57 @@ extern "C" int vd_conv3x3_wstream_supported(const VdGemmDesc* dp) {
     return wstream_reject(d) == nullptr && d.K == 9 * (d.c0 + d.c1) ? 1 : 0;
 }
 
+namespace {
+// the whole-K kernel (conv_wsk_kernel.h) takes the launch when its 128-pixel x 32-channel tiles fill at least half the chip, the
+// chunk sequence fits its unrolled loop, there is no folded skip convolution and no GroupNorm in the (absent) reduce
+bool wsk_takes(const VdGemmDesc& d, int nchunks, int nskip) {
+    const char* env = getenv("VD_WSK");   // development switch: 0 = always the split kernel + reduce launch (read per call: tests flip it)
+    if (env && env[0] == '0') return false;
+    const char* min_env = getenv("VD_WSK_MIN_BLOCKS");
+    const int min_blocks = min_env ? atoi(min_env) : 128;
+    if (d.split_k > 1) return false;   // an explicit split factor asks for the split kernel
+    if (nskip > 0 || (d.flags & VD_EPI_GROUPNORM) || nchunks < 4 || nchunks > WK_MAXC) return false;
+    if ((d.ldc & 7) || ((d.flags & VD_EPI_RESIDUAL) && (d.ldr & 7))) return false;
+    if ((d.flags & VD_EPI_RESIDUAL) && (d.flags & VD_EPI_ROWVEC) && d.act != VD_ACT_NONE) return false;
+    return (d.M / 128) * (d.N / 32) >= min_blocks;
+}
+// split factor of the split kernel for `tiles` output tiles and `nchunks` chunks (the launcher's rule)
+int wstream_split(const VdGemmDesc& d, int tiles, int nchunks, int* cps_out) {
+    int var = g_ws_variant.load(std::memory_order_relaxed), target = g_ws_blocks.load(std::memory_order_relaxed);
+    if (var < 0) {   // development switches (VD_WSTREAM_VAR / VD_WSTREAM_BLOCKS or vd_conv3x3_wstream_set_variant), read once
+        const char* var_env = getenv("VD_WSTREAM_VAR");
+        const char* tgt_env = getenv("VD_WSTREAM_BLOCKS");
+        var = var_env ? atoi(var_env) : 0;
+        target = tgt_env ? atoi(tgt_env) : 256;
+        g_ws_variant.store(var, std::memory_order_relaxed);
+        g_ws_blocks.store(target, std::memory_order_relaxed);
+    }
+    int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nchunks) nsplit = nchunks;
+    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    if (cps_out) *cps_out = cps;
+    return (nchunks + cps - 1) / cps;
+}
+}  // namespace
+
+// Split factor vd_conv3x3_wstream_f16 will use for `desc` (size the workspace with it: VdGemmDesc.split_k); 0 = the whole-K
+// kernel takes the launch and no workspace is needed.
+extern "C" int vd_conv3x3_wstream_plan(const VdGemmDesc* dp, int* nsplit) {
+    VD_REQUIRE(dp != nullptr && nsplit != nullptr, "vd_conv3x3_wstream_plan: null argument");
+    VdGemmDesc d = *dp;
+    if (d.c0 <= 0) d.c0 = d.K / 9;
+    if (d.a1 == nullptr) d.c1 = 0;
+    if (d.ldc <= 0) d.ldc = d.N;
+    if (d.ldr <= 0) d.ldr = d.N;
+    const int nchunks = (d.c0 + d.c1) / 64;
+    const int nskip = (dp->skip_a0 != nullptr) ? (dp->skip_c0 + (dp->skip_a1 ? dp->skip_c1 : 0)) / 64 : 0;
+    if (wsk_takes(d, nchunks, nskip)) { *nsplit = 0; return VD_OK; }
+    *nsplit = wstream_split(d, (d.M / 128) * (d.N / 256), nchunks, nullptr);
+    return VD_OK;
+}
+
 extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
     VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_conv3x3_wstream_f16: null argument");
     VdGemmDesc tmp = *dp;
@@ -64,7 +116,6 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     VdGemmDesc& d = a.d;
     const char* why = wstream_reject(d);
     VD_REQUIRE(why == nullptr, "vd_conv3x3_wstream_f16 takes %s", why ? why : "");
-    VD_REQUIRE(d.ws != nullptr, "vd_conv3x3_wstream_f16: needs the split-K workspace (vd_gemm_workspace_bytes)");
     VD_REQUIRE(((size_t)w_stream & 15) == 0, "vd_conv3x3_wstream_f16: w_stream must be 16-byte aligned");
     d.out_stats = dp->out_stats;
     d.sync = nullptr;
@@ -96,23 +147,37 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
         w.s0_bytes = (unsigned)((size_t)d.M * w.slda0 * 2);
         w.s1_bytes = (unsigned)((size_t)d.M * w.slda1 * 2);
     }
+    if (wsk_takes(d, w.nchunks, w.nskip)) {   // whole K per block, epilogue in the kernel: no slabs, no reduce launch
+        WkArgs k;
+        k.w = w;
+        k.w.cps = w.nchunks;
+        k.w.nsplit = 1;
+        k.w.skip_cps = 0;
+        k.g = a;
+        {
+            const char* rot_env = getenv("VD_WSK_ROTATE");   // development switch
+            k.rotate = rot_env ? atoi(rot_env) : 1;
+        }
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS);
+            if (e != hipSuccess) {
+                vd_set_error("vd_conv3x3_wstream_f16: cannot reserve %d bytes of LDS: %s", WK_LDS, hipGetErrorString(e));
+                return VD_ERR_LAUNCH;
+            }
+            done.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(conv3x3_wsk_kernel, dim3(w.tiles_m * (d.N / 32)), dim3(WK_NT), WK_LDS, stream, k);
+        return vd_check_launch("vd_conv3x3_wstream_f16/whole-K");
+    }
+    VD_REQUIRE(d.ws != nullptr, "vd_conv3x3_wstream_f16: needs the split-K workspace (vd_gemm_workspace_bytes)");
     // split over chunks until about one block per CU: 20 tiles -> 10 splits of 2 (4) chunks at the bench shape
     const int tiles = w.tiles_m * w.tiles_n;
-    int var = g_ws_variant.load(std::memory_order_relaxed), target = g_ws_blocks.load(std::memory_order_relaxed);
-    if (var < 0) {   // development switches (VD_WSTREAM_VAR / VD_WSTREAM_BLOCKS or vd_conv3x3_wstream_set_variant), read once
-        const char* var_env = getenv("VD_WSTREAM_VAR");
-        const char* tgt_env = getenv("VD_WSTREAM_BLOCKS");
-        var = var_env ? atoi(var_env) : 0;
-        target = tgt_env ? atoi(tgt_env) : 256;
-        g_ws_variant.store(var, std::memory_order_relaxed);
-        g_ws_blocks.store(target, std::memory_order_relaxed);
-    }
-    int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > w.nchunks) nsplit = w.nchunks;
-    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
-    w.cps = (w.nchunks + nsplit - 1) / nsplit;
-    nsplit = (w.nchunks + w.cps - 1) / w.cps;
+    int nsplit = wstream_split(d, tiles, w.nchunks, &w.cps);
+    const int var = g_ws_variant.load(std::memory_order_relaxed);
     w.nsplit = nsplit;
     w.skip_cps = (w.nskip + nsplit - 1) / nsplit;
     int lrc;
@@ -132,6 +197,7 @@ namespace {
 const char* gw_reject(const VdGemmDesc& d) {
     if (d.ksize > 1 || d.stride > 1 || d.pad != 0 || d.ups != 0 || d.batch != 1 || d.a1 != nullptr) return "a plain single-source, unbatched GEMM";
     if (d.M % 128 != 0 || d.N % 256 != 0 || d.K % 64 != 0) return "M % 128 == 0, N % 256 == 0, K % 64 == 0";
+    if (d.K / 64 > VD_MAX_SPLIT_K * GW_MAXC) return "K <= 65536 (the unrolled chunk sequence times the largest split)";
     if ((d.flags & (VD_EPI_LNFOLD | VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M)) || d.act == VD_ACT_GEGLU) return "a plain fp16 epilogue";
     return nullptr;
 }
@@ -142,6 +208,29 @@ extern "C" int vd_gemm_wstream_supported(const VdGemmDesc* dp) {
     VdGemmDesc d = *dp;
     if (d.batch <= 0) d.batch = 1;
     return gw_reject(d) == nullptr ? 1 : 0;
+}
+
+namespace {
+int gw_split(const VdGemmDesc& d, int tiles, int nchunks) {
+    static const char* tgt_env = getenv("VD_GEMM_WSTREAM_BLOCKS");
+    const int target = tgt_env ? atoi(tgt_env) : 256;
+    int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nchunks) nsplit = nchunks;
+    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
+    if ((nchunks + nsplit - 1) / nsplit > GW_MAXC) nsplit = (nchunks + GW_MAXC - 1) / GW_MAXC;   // the kernel unrolls its chunks
+    return nsplit;
+}
+}  // namespace
+
+// Split factor vd_gemm_wstream_f16 will use for `desc` (size the workspace with it: VdGemmDesc.split_k).
+extern "C" int vd_gemm_wstream_plan(const VdGemmDesc* dp, int* nsplit) {
+    VD_REQUIRE(dp != nullptr && nsplit != nullptr, "vd_gemm_wstream_plan: null argument");
+    const int nchunks = dp->K / 64;
+    int ns = gw_split(*dp, (dp->M / 128) * (dp->N / 256), nchunks);
+    const int cps = (nchunks + ns - 1) / ns;
+    *nsplit = (nchunks + cps - 1) / cps;
+    return VD_OK;
 }
 
 extern "C" int vd_gemm_wstream_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
@@ -171,13 +260,7 @@ extern "C" int vd_gemm_wstream_f16(const VdGemmDesc* dp, const void* w_stream, h
     w.a_bytes = a.a0_bytes;
     // split over the chunks until about one block per CU (a block = four waves, one per SIMD)
     const int tiles = w.tiles_m * w.tiles_n;
-    static const char* tgt_env = getenv("VD_GEMM_WSTREAM_BLOCKS");
-    const int target = tgt_env ? atoi(tgt_env) : 256;
-    int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > w.nchunks) nsplit = w.nchunks;
-    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
-    if ((w.nchunks + nsplit - 1) / nsplit > GW_MAXC) nsplit = (w.nchunks + GW_MAXC - 1) / GW_MAXC;   // the kernel unrolls its chunks
+    int nsplit = gw_split(d, tiles, w.nchunks);
     VD_REQUIRE(nsplit <= VD_MAX_SPLIT_K, "vd_gemm_wstream_f16: K = %d needs more than %d splits", d.K, VD_MAX_SPLIT_K);
     w.cps = (w.nchunks + nsplit - 1) / nsplit;
     nsplit = (w.nchunks + w.cps - 1) / w.cps;

@@ -101,7 +101,7 @@ struct EpiCtx {
     const f16* rowvec;
     const f16* res;
     void* out;
-    float* row_sums;   // VdGemmDesc.row_sums (gemm_f16_kernel's part 2 only), else null
+    unsigned long long* row_sums;   // VdGemmDesc.row_sums (gemm_f16_kernel's part 2 only), else null
     int N, ldc, ldr, rows_per_batch, flags, act;
     float alpha;
 };
@@ -115,8 +115,7 @@ __device__ __forceinline__ EpiCtx make_epi(const VdGemmDesc& d, int z) {
         e.out = reinterpret_cast<float*>(d.out) + (size_t)z * d.stride_out;
     else
         e.out = reinterpret_cast<f16*>(d.out) + (size_t)z * d.stride_out;
-    e.row_sums = d.row_sums + (size_t)z * d.M * 2;
-    if (d.row_sums == nullptr) e.row_sums = nullptr;
+    e.row_sums = d.row_sums == nullptr ? nullptr : reinterpret_cast<unsigned long long*>(d.row_sums) + (size_t)z * d.M * 2;
     e.N = (d.act == VD_ACT_GEGLU) ? d.N / 2 : d.N;
     e.ldc = d.ldc;
     e.ldr = d.ldr;
@@ -358,16 +357,34 @@ __device__ __forceinline__ void epi_load_bias(const EpiCtx& e, int N, int col0, 
             b[j * 4 + g].u = make_uint2(v[0], v[1]);
         }
 }
+// Row statistics of the LayerNorm fold, one 16-byte request per row whatever the source (no branch around the requests):
+// (mean, rstd) fp32 from vd_row_stats_f16 in .x / .y, or -- VD_EPI_LN_SUMS -- the producer's row_sums, two int64 fixed-point
+// sums (ln_sums_decode).  The descriptor ends with the table, so the 8 bytes past the last (mean, rstd) pair read as zeros.
 template <int MI>
-__device__ __forceinline__ void epi_load_lnstats(const float* ln_stats, int M, int z, int row0, float2* st, bool enable) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ln_stats), 0, (enable && ln_stats != nullptr) ? 0x7fffffff : 0, 0x00020000);
+__device__ __forceinline__ void epi_load_lnstats(const float* ln_stats, int M, int z, int row0, uint4* st, bool enable, bool sums, int rows_total) {
+    const int rb = sums ? 16 : 8;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ln_stats), 0, (enable && ln_stats != nullptr) ? rows_total * rb : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int row = row0 + i * 32;
-        const vd_u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(row < M ? (unsigned)((z * M + row) * 8) : OOB_OFFSET), 0, 0);
-        const unsigned vx = v[0], vy = v[1];   // (never __builtin_bit_cast a swizzle: clang reads element 0 for both)
-        st[i] = make_float2(__uint_as_float(vx), __uint_as_float(vy));
+        const vd_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row < M ? (unsigned)((z * M + row) * rb) : OOB_OFFSET), 0, 0);
+        st[i] = make_uint4(v[0], v[1], v[2], v[3]);   // (never __builtin_bit_cast a swizzle: clang reads element 0 for both)
     }
+}
+// VdGemmDesc.row_sums: fixed point so that the atomic accumulation is ORDER-INDEPENDENT (integer adds): the same inputs give
+// the same bits in every run (fp32 atomics made two runs of one UNet forward differ by 1.4e-3 rel-L2 -- the fp16 rounding flips
+// a 1e-7 perturbation of a LayerNorm triggers downstream).  sum x 2^24, sum of squares x 2^16 in int64: |row sum| < 2^38,
+// sum of squares < 2^46 (1280 columns of |x| <= 65504 need 2^23 and 2^43).
+constexpr float LN_SUM_SCALE = 16777216.0f, LN_SQ_SCALE = 65536.0f;
+__device__ __forceinline__ void ln_sums_decode(const uint4 raw, int K, float eps, float& rstd, float& nmr) {
+    const long long S1 = (long long)(((unsigned long long)raw.y << 32) | raw.x);
+    const long long S2 = (long long)(((unsigned long long)raw.w << 32) | raw.z);
+    const float inv_k = 1.0f / (float)K;
+    const float mean = (float)S1 * (1.0f / LN_SUM_SCALE) * inv_k;
+    float var = (float)S2 * (1.0f / LN_SQ_SCALE) * inv_k - mean * mean;
+    if (var < 0.f) var = 0.f;
+    rstd = rsqrtf(var + eps);
+    nmr = -mean * rstd;
 }
 
 // keep: the stored values are also written back into the tile (the statistics pass behind part 2 reads them there)
@@ -433,9 +450,9 @@ __device__ __forceinline__ void epi_writeout(const EpiCtx& e, int M, int m0, int
                     s1 += __shfl_xor(s1, sh, 64);
                     s2 += __shfl_xor(s2, sh, 64);
                 }
-                if (ok && (c % CH) == 0) {
-                    atomicAdd(e.row_sums + (size_t)row * 2, s1);
-                    atomicAdd(e.row_sums + (size_t)row * 2 + 1, s2);
+                if (ok && (c % CH) == 0) {   // fixed point: integer adds commute exactly (ln_sums_decode)
+                    atomicAdd(e.row_sums + (size_t)row * 2, (unsigned long long)__float2ll_rn(s1 * LN_SUM_SCALE));
+                    atomicAdd(e.row_sums + (size_t)row * 2 + 1, (unsigned long long)__float2ll_rn(s2 * LN_SQ_SCALE));
                 }
             }
             return;
@@ -574,11 +591,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     uint4 pre_h[HOIST ? MAX_CH_H : 1];
     constexpr bool BIAS_ALL = NI <= 2;       // wider wave tiles request the bias per 32-column group (4 requests at a time)
     U2H4 bias_r[BIAS_ALL ? NI * 4 : 4];
-    float2 lnst_r[MI];
+    uint4 lnst_r[MI];
+    const bool ln_sums = (d.flags & VD_EPI_LN_SUMS) != 0;
     if constexpr (HOIST) {
         epi_prefetch<BM, BN / 8, NT, MAX_CH_H, WM, WM>(e, d.M, m0, 0, n0, tid, pre_h, hoisted);
         epi_load_bias<NI>(e, d.N, n0 + wn * WN + 4 * hi, bias_r, hoisted);
-        if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, hoisted);
+        if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, hoisted, ln_sums, d.M * d.batch);
     }
 
     // LayerNorm fold: the block's BN entries of colsum wait in LDS behind the stages / the epilogue tile, so the epilogue's
@@ -1110,7 +1128,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         else epi_prefetch<PROWS, BN / 8, NT, MAX_CH, SEG, WM>(e, d.M, m0, ep * SEG, out_n0, tid, pre);
         if (ep == 0) {   // bias / LayerNorm statistics of the whole wave tile, requested back to back behind the segments
             if constexpr (BIAS_ALL) epi_load_bias<NI>(e, d.N, n0 + wn * WN + 4 * hi, bias_r, true);
-            if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, true);
+            if constexpr (LNF) epi_load_lnstats<MI>(d.ln_stats, d.M, z, m0 + wm * WM + l31, lnst_r, true, ln_sums, d.M * d.batch);
         }
     }
     const bool bias_fast = (d.N & 3) == 0;
@@ -1133,17 +1151,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
                 ln_rstd = rsqrtf(var + d.ln_eps);
                 ln_nmr = -mean * ln_rstd;
             } else {
-                const float2 st = lnst_r[i];
-                if (d.flags & VD_EPI_LN_SUMS) {   // (sum, sum of squares) from the producer's row_sums
-                    const float inv_k = 1.0f / (float)d.K;
-                    const float mean = st.x * inv_k;
-                    float var = st.y * inv_k - mean * mean;
-                    if (var < 0.f) var = 0.f;
-                    ln_rstd = rsqrtf(var + d.ln_eps);
-                    ln_nmr = -mean * ln_rstd;
+                const uint4 st = lnst_r[i];
+                if (ln_sums) {   // (sum, sum of squares) from the producer's row_sums
+                    ln_sums_decode(st, d.K, d.ln_eps, ln_rstd, ln_nmr);
                 } else {
-                    ln_rstd = st.y;
-                    ln_nmr = -st.x * st.y;
+                    ln_rstd = __uint_as_float(st.y);
+                    ln_nmr = -__uint_as_float(st.x) * ln_rstd;
                 }
             }
         }

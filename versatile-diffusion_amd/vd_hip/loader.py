@@ -49,6 +49,8 @@ PROTOTYPES = {
     "vd_gemm_row_sums_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_gemm_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
+    "vd_conv3x3_wstream_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
+    "vd_gemm_wstream_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),

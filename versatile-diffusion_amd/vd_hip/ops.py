@@ -187,13 +187,13 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     skip = (s0, s1 or None, w_skip [N, C_s0 + C_s1]): a 1x1 convolution of cat(s0, s1) on the output grid folded into this 3x3
     convolution as extra K (ResBlock's skip_connection(x) + h; its bias belongs into `bias`).  Returns None WITHOUT launching
     when the planned launch cannot take it (vd_gemm_skip_ok): the caller then runs the 1x1 convolution itself.
-    row_sums: zeroed fp32 [M, 2] (rowsum_take): the epilogue adds (sum, sum of squares) of every stored row -- the statistics of
+    row_sums: zeroed int64 [M, 2] (rowsum_take; fixed point, see VdGemmDesc.row_sums): the epilogue adds (sum, sum of squares) of every stored row -- the statistics of
     the LayerNorm folded into the NEXT projection; comes back as `out._vd_rowsums` when the planned launch can accumulate them
     (vd_gemm_row_sums_ok), else the attribute is absent and the consumer runs vd_row_stats_f16.
     ln_sums: with colsum, such a buffer describing the rows of a0 (VD_EPI_LN_SUMS) instead of the row_stats launch.
     """
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
-    _req(colsum, "colsum", torch.float32); _req(row_sums, "row_sums", torch.float32); _req(ln_sums, "ln_sums", torch.float32)
+    _req(colsum, "colsum", torch.float32); _req(row_sums, "row_sums", torch.int64); _req(ln_sums, "ln_sums", torch.int64)
     if out is not None:   # a re-used output tensor must not keep the statistics of what it held before
         for attr in ("_vd_stats", "_vd_normalized", "_vd_rowsums"):
             if hasattr(out, attr):
@@ -300,17 +300,22 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk_stream.data_ptr()
             d.skip_lda0, d.skip_lda1 = d.skip_c0, d.skip_c1
         d.split_k = int(split_k)
-        d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
-        stats = None
         fused_gn = gn_on and bool(lib().vd_gemm_groupnorm_ok(ctypes.byref(d), 1))
         if fused_gn:
             d.flags = flags | gn_flags
+        # the launcher's own split (0: the whole-K kernel, no slabs at all) sizes the workspace -- not the 32-slab upper bound
+        pns = ctypes.c_int(0)
+        _check(lib().vd_conv3x3_wstream_plan(ctypes.byref(d), ctypes.byref(pns)))
+        if pns.value > 0:
+            d.split_k = pns.value
+            d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
+        stats = None
         if want_stats and not fused_gn:
             sbuf = torch.empty((int(M) // 64, n_out, 2), dtype=torch.float32, device=a0.device)
             d.out_stats = sbuf.data_ptr()
             stats = ChanStats(sbuf, 1, n_out, 64)
         extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
-        nm = "conv3x3_wstream_kernel + reduce"
+        nm = "conv3x3_wstream_kernel + reduce" if pns.value > 0 else "conv3x3_wsk_kernel"
         if PROFILE_SHAPES:
             nm += " M=%d N=%d K=%d" % (M, N, K)
         with _Timed(nm, 2.0 * M * N * K, 2.0 * (float(M) * (d.c0 + d.c1) + float(N) * K + float(M) * n_out + extra)):
@@ -325,6 +330,9 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         # long-K, small-M projection: weights in fragment order straight into registers (gemm_wstream_kernel.h) + reduce
         _req(w_stream, "w_stream")
         d.split_k = int(split_k)
+        pns = ctypes.c_int(0)
+        _check(lib().vd_gemm_wstream_plan(ctypes.byref(d), ctypes.byref(pns)))
+        d.split_k = max(pns.value, 1)   # the launcher's own split sizes the workspace (not the 32-slab upper bound)
         d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
         stats = None
         nm = "gemm_wstream_kernel + reduce"
@@ -430,7 +438,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
 
 
 # LayerNorm row statistics from the producer (round 5): the GEMM that STORES the rows a folded LayerNorm will normalise adds
-# (sum, sum of squares) per row into a zeroed fp32 [rows, 2] buffer (VdGemmDesc.row_sums), the consumer reads it with
+# (sum, sum of squares) per row into a zeroed int64 [rows, 2] fixed-point buffer (VdGemmDesc.row_sums), the consumer reads it with
 # VD_EPI_LN_SUMS -- the 22 vd_row_stats_f16 launches of a UNet forward (and their extra read of x) disappear.  The buffers of
 # one forward are slices of ONE arena zeroed by one fill (RowSumArena, begun by vd.run_unet); VD_LN_SUMS=0: row_stats launches.
 LN_SUMS = os.environ.get("VD_LN_SUMS", "1") != "0"
@@ -438,7 +446,7 @@ _tls = threading.local()
 
 
 class RowSumArena(object):
-    """Bump allocator over one zeroed fp32 [need, 2] tensor per forward; `need` is what the previous forward of this owner
+    """Bump allocator over one zeroed int64 [need, 2] tensor per forward; `need` is what the previous forward of this owner
     took (the first forward, and any request beyond it, falls back to a torch.zeros of its own)."""
 
     def __init__(self):
@@ -446,7 +454,7 @@ class RowSumArena(object):
 
     def begin(self, device):
         self.used = 0
-        self.buf = torch.zeros((self.need, 2), dtype=torch.float32, device=device) if self.need > 0 else None
+        self.buf = torch.zeros((self.need, 2), dtype=torch.int64, device=device) if self.need > 0 else None
         _tls.arena = self
 
     def take(self, rows, device):
@@ -454,7 +462,7 @@ class RowSumArena(object):
         start, self.used = self.used, self.used + rows
         if self.buf is not None and self.used <= self.buf.shape[0] and self.buf.device == device:
             return self.buf[start:start + rows]
-        return torch.zeros((rows, 2), dtype=torch.float32, device=device)
+        return torch.zeros((rows, 2), dtype=torch.int64, device=device)
 
     def end(self):
         self.need, self.buf = self.used, None
@@ -462,13 +470,13 @@ class RowSumArena(object):
 
 
 def rowsum_take(rows, device):
-    """Zeroed fp32 [rows, 2] for VdGemmDesc.row_sums, or None when producer row statistics are switched off."""
+    """Zeroed int64 [rows, 2] for VdGemmDesc.row_sums, or None when producer row statistics are switched off."""
     if not LN_SUMS:
         return None
     arena = getattr(_tls, "arena", None)
     if arena is not None:
         return arena.take(rows, device)
-    return torch.zeros((int(rows), 2), dtype=torch.float32, device=device)
+    return torch.zeros((int(rows), 2), dtype=torch.int64, device=device)
 
 
 SKIP_FOLD = os.environ.get("VD_SKIP_FOLD", "1") != "0"   # ResBlock skip 1x1 convolution as extra K of the second 3x3 conv
