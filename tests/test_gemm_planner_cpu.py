@@ -275,3 +275,62 @@ def test_which_projections_take_the_weight_streaming_gemm():
     assert ok(2048, 1280, 5120, act=1) == 0  # GEGLU epilogue
     assert ok(2048, 1280, 5120, a1=16, c1=64) == 0   # two-source A
     assert ok(2048, 1280, 5120, ksize=3, stride=1, pad=1) == 0
+
+
+def test_which_8x8_convolutions_run_without_a_split_and_which_launches_take_row_sums(monkeypatch):
+    """Round 5, host decisions only: vd_conv3x3_wstream_plan answers 0 (whole-K kernel: no workspace, no reduce launch) for the
+    8x8-level convolutions whose 128-pixel x 32-channel tiles cover half the chip, the launcher's split otherwise (folded skip
+    convolution, too few image groups, explicit split, VD_WSK=0); vd_gemm_row_sums_ok admits VdGemmDesc.row_sums exactly for
+    unsplit gemm_f16_kernel launches with vector-aligned fp16 output and power-of-two segment counts per tile row."""
+    from vd_hip.loader import VdGemmDesc, lib
+
+    def conv8(B, cin, n=1280, skip=0, split=0, flags=0):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = B * 64, n, 9 * cin
+        d.a0 = d.w = d.out = 16
+        d.Hin = d.Win = d.Hout = d.Wout = 8
+        d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, cin
+        d.split_k, d.flags = split, flags
+        if skip:
+            d.skip_a0 = d.skip_w = 16
+            d.skip_c0 = skip
+        ns = ctypes.c_int(-1)
+        assert lib().vd_conv3x3_wstream_plan(ctypes.byref(d), ctypes.byref(ns)) == 0
+        return ns.value
+
+    monkeypatch.delenv("VD_WSK", raising=False)
+    monkeypatch.delenv("VD_WSK_MIN_BLOCKS", raising=False)
+    assert conv8(8, 1280) == 0 and conv8(8, 2560) == 0         # bench shape: 4 image groups x 40 column tiles = 160 blocks
+    assert conv8(8, 1280, skip=2560) == 10                      # the folded skip convolution stays on the split kernel
+    assert conv8(4, 1280) == 20                                 # 80 whole-K tiles < 128: 10 split-kernel tiles x 20 one-chunk splits
+    assert conv8(8, 1280, split=5) == 5                         # an explicit split factor is honoured
+    assert conv8(8, 128) == 2                                   # 2 chunks: below the whole-K kernel's pipeline depth
+    assert conv8(8, 1280, flags=128) == 10                      # VD_EPI_GROUPNORM lives in the reduce kernel
+    monkeypatch.setenv("VD_WSK", "0")
+    assert conv8(8, 1280) == 10
+
+    def rs_ok(M, N, K, res=False, rowvec=False, act=0, f32=False, ks=1, ws=False):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.a0 = d.w = d.out = 16
+        d.act = act
+        d.flags = (4 if res else 0) | (2 if rowvec else 0) | (16 if f32 else 0)
+        if res:
+            d.res = 16
+        if rowvec:
+            d.rowvec, d.rows_per_batch = 16, M
+        if ks == 3:
+            h = int(round((M // 8) ** 0.5))
+            d.Hin = d.Win = d.Hout = d.Wout = h
+            d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, K // 9
+        d.ws = 16 if ws else None
+        return lib().vd_gemm_row_sums_ok(ctypes.byref(d))
+
+    for (M, C) in ((8192, 640), (2048, 1280), (512, 1280)):     # to_out / proj_in of the 32x32 .. 8x8 levels
+        assert rs_ok(M, C, C, res=True) == 1 and rs_ok(M, C, C) == 1
+    assert rs_ok(8192, 5120, 640, act=1) == 0                   # GEGLU output is not the row a LayerNorm normalises
+    assert rs_ok(8192, 640, 640, f32=True) == 0
+    assert rs_ok(8192, 640, 640, res=True, rowvec=True) == 0    # both operands: the element-wise write-out path
+    assert rs_ok(32768, 320, 2880, ks=3) == 0                   # halo-resident convolution: another epilogue
+    assert rs_ok(2048, 1280, 5120, ws=True) in (0, 1)           # (whatever the planner picks, the answer is consistent with ...)
+    assert rs_ok(8192, 644, 640) == 0                           # N % 8 != 0

@@ -876,3 +876,32 @@ def test_dual_context_guided_10_step_graph_loop_batch2_vs_oracle(full, dev, monk
     # step 0 of the first call ran eagerly, here it is replayed: the same kernels (the 4x4 level measures its GroupNorms through
     # LDS float atomics, so the last bit is order-dependent)
     assert rel_l2(z2, z) < 2e-3
+
+
+def test_hoisted_time_embedding_matches_in_step_embedding(tiny, dev, monkeypatch):
+    """DDIMSampler computes the t-only part of the UNet (time-embedding MLP + every ResBlock's emb_layers projection, reference
+    vd.py:339-349 / openaimodel.py:2627-2633, :263) for all steps once per sample() and hands the step graph one row of that
+    table (VD_v2_0.precompute_step_emb); with emb_hoist off every step recomputes it like the reference.  Same latents either
+    way, single- and multi-context, and apply_model with the extension key equals apply_model without it."""
+    from lib.model_zoo.ddim import DDIMSampler
+    gd = load_gold("ddim_tiny.npz")
+    xT = torch.from_numpy(gd["xT"]).half().to(dev)
+    ct, ut = torch.from_numpy(gd["c_text"]).half().to(dev), torch.from_numpy(gd["u_text"]).half().to(dev)
+    ci = {"type": "text", "conditioning": ct, "unconditional_conditioning": ut, "unconditional_guidance_scale": 7.5}
+    outs = []
+    for hoist in (True, False):
+        s = DDIMSampler(tiny)
+        s.emb_hoist = hoist
+        z, _ = s.sample(steps=6, shape=list(xT.shape), x_info={"type": "image", "xt": xT.clone()}, c_info=dict(ci), eta=0., verbose=False)
+        outs.append(z)
+    assert rel_l2(outs[0], outs[1]) < 2e-3
+    # one forward: the extension key against the in-forward embedding
+    t = torch.full((xT.shape[0],), 601, device=dev, dtype=torch.long)
+    pre = tiny.precompute_step_emb("image", t[:1])
+    assert pre is not None
+    row = pre[0][0]
+    rows = {di: row[o:o + c] for di, (o, c) in pre[1].items()}
+    e0 = tiny.apply_model({"type": "image", "x": xT}, t, {"type": "text", "c": ct})
+    e1 = tiny.apply_model({"type": "image", "x": xT, "emb_rows": rows}, t, {"type": "text", "c": ct})
+    assert rel_l2(e1, e0) < 2e-3
+    assert tiny.precompute_step_emb("text", t[:1]) is None   # the 0-D text-latent flow keeps its in-forward embedding

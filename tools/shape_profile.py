@@ -10,17 +10,29 @@ from vd_hip import ops
 dev = torch.device("cuda:0")
 net = bench.build_model(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+MODE = sys.argv[2] if len(sys.argv) > 2 else "t2i"   # "dual": BASELINE configs[3] per-GPU share (text 77 + image 257, mixed 0.5 / 0.5)
 x = torch.randn(2 * B, 4, 64, 64, device=dev, dtype=torch.float16)
 t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
 c = torch.randn(2 * B, 77, 768, device=dev, dtype=torch.float16) * 0.5
+ci = torch.randn(2 * B, 257, 768, device=dev, dtype=torch.float16) * 0.5
+_kv = [{}, {}]
+
+
+def forward():
+    if MODE == "dual":
+        return net.apply_model_multicontext({"type": "image", "x": x}, t, [{"type": "text", "c": c, "ratio": 0.5, "kv_cache": _kv[0]},
+                                                                           {"type": "image", "c": ci, "ratio": 0.5, "kv_cache": _kv[1]}])
+    return net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+
+
 for _ in range(2):
-    net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+    forward()
 ops.PROFILE_SHAPES = True
 agg = {}
 reps = 5
 for _ in range(reps):
     ops.profile_begin()
-    net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+    forward()
     for name, fl, by, ms in ops.profile_end():
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += fl; a[2] += ms

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                 __builtin_amdgcn_s_sleep(8);
                 // never seen (ticket holders are resident).  A bounded wait cannot hang the device, and giving up must not
                 // look like success: trap -- the launch fails, the host sees the error, the counters are NOT re-armed
-                if (++spins > (1u << 18)) __builtin_trap();
+                if (++spins > (1u << 24)) __builtin_trap();
             }
             if (local) {   // re-arm for the next launch
                 l2_add(ticket_ctr, -nsplit);

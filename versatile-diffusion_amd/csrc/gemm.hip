@@ -907,8 +907,10 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         if (nsplit <= 1 || 2l * halo.g.tiles_m * halo.g.tiles_n > VD_GEMM_SYNC_INTS) halo.g.d.sync = nullptr;
         {   // ticketed split: blocks are dispatched round-robin over the 8 XCDs in linear order (x fastest); with a tile count
             // that is a multiple of 8 every split of a tile (same blockIdx.x) lands on XCD blockIdx.x % 8
-            static const char* loc_env = getenv("VD_HALO_XCD_LOCAL");   // development switch: 0 = device-scope exchange
-            const bool want = !(loc_env && loc_env[0] == '0');
+            // opt-in: the L2-scope exchange is only safe while block b is dispatched to XCD b % 8, which HIP does not
+            // promise (partition modes, CU masks); the default ticketed path exchanges at agent scope
+            static const char* loc_env = getenv("VD_HALO_XCD_LOCAL");   // development switch: 1 = exchange through the XCD's L2
+            const bool want = loc_env && loc_env[0] == '1';
             halo.g.xcd_local = (want && halo.g.d.sync != nullptr && ((long)halo.g.tiles_m * halo.g.tiles_n) % 8 == 0) ? 1 : 0;
         }
         rc = vd_conv_halo_launch(&halo, cfg - T_COUNT, nsplit, stream);

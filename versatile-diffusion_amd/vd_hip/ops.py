@@ -72,7 +72,11 @@ class _Timed(object):
         return False
 
 
+LIB_CALLS = [0]   # calls into the C ABI that enqueue work (every launcher takes the stream exactly once): bench.py reports the count per step
+
+
 def _stream():
+    LIB_CALLS[0] += 1
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -111,7 +115,7 @@ FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
 # opt-in (VD_HALO_FIXUP=1): the halo conv reduces its channel-chunk split in-kernel through ticket counters instead of the
 # reduce launch.  Correct, not faster: equal at a 2-way split, 9 us slower per conv at 4-way, forward 11.98 vs 11.93 ms.
 HALO_FIXUP_MAXSPLIT = int(os.environ.get("VD_HALO_FIXUP_MAXSPLIT", "32"))   # ... only for splits up to this factor
-HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"   # round 4: with the XCD-local exchange (VD_HALO_XCD_LOCAL, default on)
+HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"   # (VD_HALO_XCD_LOCAL=1 adds the L2-scope exchange: opt-in, it relies on block -> XCD placement)
 
 
 def sync_counters(device):
@@ -151,8 +155,16 @@ class ChanStats(object):
 
 
 def stats_of(t):
-    """ChanStats attached to tensor `t` by its producer, or None."""
-    return getattr(t, "_vd_stats", None) if t is not None else None
+    """ChanStats attached to tensor `t` by its producer, or None.  Statistics that do not describe `t` (stale attribute on a
+    re-used or reshaped tensor: other channel count, rows per sample or batch) are dropped -- the consumer then measures `t`."""
+    st = getattr(t, "_vd_stats", None) if t is not None else None
+    if st is None:
+        return None
+    C = t.shape[-1]
+    rows = t.numel() // max(C, 1)   # (a producer may hand the tensor over as [rows, C]: samples x rows per sample is what counts)
+    if st.C != C or st.T <= 0 or (st.buf.shape[0] // st.T) * st.HW != rows or st.buf.device != t.device:
+        return None
+    return st
 
 
 def repeat_batch(t, repeat):
@@ -540,8 +552,13 @@ ST_CHAIN = os.environ.get("VD_ST_CHAIN", "1") != "0"   # round 4: on -- with the
 
 
 def st_chain_supported(B, HW, C, inner):
-    """True when vd_gemm_row320_chain_f16 can take the entry of a SpatialTransformer (width 320, row blocks fill the chip)."""
-    return ST_CHAIN and ROW320 and C == 320 and inner == 320 and HW % 128 == 0 and B * HW // 128 >= 192
+    """True when vd_gemm_row320_chain_f16 can take the entry of a SpatialTransformer (width 320, row blocks cover at least half
+    of the device's CUs: at CFG batch 4 -- BASELINE configs[3]'s per-GPU share -- the one launch on 128 CUs still beats the
+    gn_from_stats + proj_in + q|k|v launches it replaces, 14.5 + 19.6 + 36.4 us in profiles/r05_dual_per_shape.txt)."""
+    if not (ST_CHAIN and ROW320 and C == 320 and inner == 320 and HW % 128 == 0):
+        return False
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+    return B * HW // 128 >= cus // 2
 
 
 def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5):
@@ -680,6 +697,8 @@ def _from_stats_ok(C, groups):
     if C % groups != 0 or C % 8 != 0:
         return False
     cg = C // groups
+    if cg > 128 or C > 4096:   # limits of vd_gn_table_f32 (channels per group) and vd_gn_apply_table_f16 (row width)
+        return False
     s = cg
     while s % 8:
         s += cg
