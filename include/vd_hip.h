@@ -258,6 +258,36 @@ int vd_groupnorm_affine_f16(const void* x, const void* gamma, const void* beta, 
 int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void* b1_packed, const void* w2, const void* b2,
                     const void* res, void* y, int64_t M, int C, float ln_eps, hipStream_t stream);
 int vd_ff_geglu_supported(int C);
+/* The same feed-forward with the C x C projections on either side of it in the SAME launch (ABI 6, C = 320:
+ * vd_ff_chain_supported) -- the row-local tail of a 64x64-level transformer block,
+ *     x1  = a wo^T + bo + x                 (given a: CrossAttention.to_out + residual, attention.py:192-193,216)
+ *     y   = x1 + FF(LayerNorm(x1))           (attention.py:37-64,217)
+ *     out = alpha (y wp^T + bp) + res        (given wp: SpatialTransformer.proj_out + skip / context mixing, attention.py:262-266)
+ * instead of vd_gemm_f16 -> vd_ff_geglu_f16 -> vd_gemm_f16.  Without `a` the feed-forward reads x itself; without `wp` it
+ * stores y.  x1_scratch: [M][C] fp16 the kernel parks x1 in (needed with `a`).  out_stats (with wp, M % 128 == 0): fp32
+ * [M / 128][C][2] per-channel (mean, M2) over blocks of 128 stored rows, the VdGemmDesc.out_stats format with R = 128. */
+typedef struct VdFfChain {
+    const void* x;          /* fp16 [M][C] */
+    const void* a;          /* fp16 [M][C] or NULL */
+    const void* wo;         /* fp16 [C][C] */
+    const void* bo;         /* fp16 [C] */
+    void* x1_scratch;       /* fp16 [M][C] */
+    const void* w1_packed;  /* fp16 [8C][C]: LayerNorm-folded, GEGLU-packed (as vd_ff_geglu_f16) */
+    const void* b1_packed;  /* fp16 [8C] */
+    const void* w2;         /* fp16 [C][4C] */
+    const void* b2;         /* fp16 [C] */
+    const void* wp;         /* fp16 [C][C] or NULL */
+    const void* bp;         /* fp16 [C] */
+    const void* res;        /* fp16 [M][C]: residual of the last projection */
+    void* out;              /* fp16 [M][C] */
+    float* out_stats;       /* or NULL */
+    int64_t M;
+    int32_t C;
+    float ln_eps, alpha;
+    int32_t reserved;
+} VdFfChain;
+int vd_ff_chain_f16(const VdFfChain* chain, hipStream_t stream);
+int vd_ff_chain_supported(int C);
 
 /* GroupNorm(groups) [+ SiLU] over channels-last input that may be the concatenation of two tensors.
  * stats is a caller-provided fp32 scratch of vd_groupnorm_workspace_bytes().

@@ -221,6 +221,56 @@ def test_gemm_layernorm_fold(ops, dev, M, K, N, offset, inloop, monkeypatch):
     assert rel_l2(out, ref - b.float() - res.float()) < 3e-3
 
 
+@pytest.mark.parametrize("M,pre,post,offset", [(128, True, True, 0.0), (1000, True, False, 0.5), (4096, False, True, -1.0), (4096 + 40, True, True, 0.0),
+                                               (8192, True, True, 2.0)])
+def test_ff_chain(ops, dev, M, pre, post, offset):
+    """vd_ff_chain_f16 (round 5): attn2.to_out + residual -> LayerNorm -> GEGLU feed-forward -> + residual -> proj_out (alpha, +
+    residual, per-channel statistics) in one launch (C = 320) against torch fp32 and against the library's own separate launches
+    (vd_gemm_f16 -> vd_ff_geglu_f16 -> vd_gemm_f16); either projection alone as well."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    from vd_hip.pack import pack_geglu
+    C = 320
+    assert ops.ff_chain_supported(C)
+    x0 = rnd((M, C), dev, 1.2, 900) + offset
+    a = rnd((M, C), dev, 1.0, 901)
+    wo, bo = rnd((C, C), dev, 0.05, 902), rnd((C,), dev, 0.2, 903)
+    w1, b1 = rnd((8 * C, C), dev, 0.05, 904), rnd((8 * C,), dev, 0.2, 905)
+    w2, b2 = rnd((C, 4 * C), dev, 0.03, 906), rnd((C,), dev, 0.2, 907)
+    wp, bp = rnd((C, C), dev, 0.05, 908), rnd((C,), dev, 0.2, 909)
+    r = rnd((M, C), dev, 1.0, 910)
+    alpha = 0.4
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(911)).to(dev))
+        ln.bias.copy_(0.1 * torch.randn(C, generator=torch.Generator().manual_seed(912)).to(dev))
+    x1 = (a.float() @ wo.float().t() + bo.float() + x0.float()) if pre else x0.float()
+    x1h = x1.half().float()   # the kernel parks x1 in fp16
+    xn = F.layer_norm(x1h, (C,), ln.weight.float(), ln.bias.float(), 1e-5)
+    v, g = (xn @ w1.float().t() + b1.float()).chunk(2, dim=-1)
+    y = x1h + (v * F.gelu(g)) @ w2.float().t() + b2.float()
+    ref = alpha * (y.half().float() @ wp.float().t() + bp.float()) + r.float() if post else y
+    wf, bf, _ = fold_layernorm(w1, b1, ln)
+    w1p, b1p = pack_geglu(wf, bf)
+    kw = {}
+    if pre:
+        kw.update(a=a, wo=wo, bo=bo)
+    if post:
+        kw.update(wp=wp, bp=bp, alpha=alpha, res=r, want_stats=True, stat_img_rows=M if M % 128 == 0 else 0)
+    out = ops.ff_chain(x0, w1p, b1p, w2, b2, 1e-5, **kw)
+    assert out.shape == ref.shape and rel_l2(out, ref) < 3e-3
+    # the separate launches of the library
+    xs = ops.gemm(a, wo, bias=bo, res=x0) if pre else x0
+    ys = ops.ff_geglu(xs, w1p, b1p, w2, b2, xs, 1e-5)
+    os_ = ops.gemm(ys, wp, bias=bp, alpha=alpha, res=r) if post else ys
+    assert rel_l2(out, os_) < 3e-3
+    st = ops.stats_of(out)
+    if post and M % 128 == 0:
+        assert st is not None and st.T == M // 128 and st.HW == M
+        _stats_close(st, _chan_stats_ref(out.view(1, M, C), 1, M // 128), 128)
+    else:
+        assert st is None
+
+
 @pytest.mark.parametrize("M,N,K,res,conv", [(8192, 640, 640, True, False), (2048, 1280, 1280, True, False), (512, 1280, 1280, False, True),
                                            (8192 + 24, 640, 640, False, False), (2048, 1280, 320, True, False)])
 def test_gemm_row_sums_feed_the_layernorm_fold(ops, dev, M, N, K, res, conv):

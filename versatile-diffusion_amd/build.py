@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
 OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "conv_wstream.hip", "ff_fused.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "conv_wstream.hip", "ff_fused.hip", "ff_chain.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "conv_halo_kernel.h"), os.path.join(CSRC, "conv_wstream_kernel.h"), os.path.join(CSRC, "conv_wreg_kernel.h"), os.path.join(CSRC, "gemm_wstream_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the
@@ -25,6 +25,7 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "conv_halo.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "ff_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "ff_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "gemm_row320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

@@ -50,6 +50,16 @@ class FeedForward(nn.Module):
         dim_out = dim if dim_out is None else dim_out
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), Linear(inner, dim_out))
 
+    def chain_operands(self, ln):
+        """(w1 packed, b1 packed, w2, b2) of the one-launch kernels, or None when this feed-forward does not fit them."""
+        proj, out = self.net[0].proj, self.net[2]
+        C = proj.in_features
+        if out.bias is None or proj.bias is None or out.out_features != C or out.in_features != 4 * C:
+            return None
+        wp, bp, _ = self.net[0].folded(ln)
+        w2, b2 = out._w()
+        return wp, bp, w2, b2
+
     def forward(self, x, res=None, ln=None, ln_sums=None):
         """ln: the LayerNorm in front (folded); ln_sums: row statistics of x from its producer (ops.gemm(row_sums=...)).  Where the library has the one-launch kernel for this width (C = 320: the
         64x64 level, whose [M, 4C] GEGLU intermediate is 84 MB) LayerNorm, both projections, the gating and the residual
@@ -100,9 +110,11 @@ class CrossAttention(nn.Module, PackCache):
         return self._packed("q_ln", (self.to_q.weight, ln.weight, ln.bias),
                             lambda: fold_layernorm(_h(self.to_q.weight), None, ln))
 
-    def forward(self, x, context=None, res=None, kv=None, ln=None, qkv=None, ln_sums=None, out_sums=None):
+    def forward(self, x, context=None, res=None, kv=None, ln=None, qkv=None, ln_sums=None, out_sums=None, defer_out=False):
         """ln_sums: row statistics of x for `ln` (from x's producer); out_sums: zeroed fp32 [rows, 2] the output projection
         accumulates the row statistics of ITS output into (for the LayerNorm in front of the next block part).
+        defer_out: return the attention output `a` WITHOUT the output projection (the caller folds to_out + res into its next
+        launch: ops.ff_chain); only honoured on the one-launch cross-attention path, else the projected tensor comes back as usual.
         x [B, N, C] -> to_out(attn) (+ res fused).  ln: the LayerNorm in front of the block's q (and self k / v)
         projections, folded into them -- x is then the un-normalised input.  qkv: the fused self-attention projection when
         the caller has already computed it (SpatialTransformer's chained entry kernel)."""
@@ -123,6 +135,9 @@ class CrossAttention(nn.Module, PackCache):
                 # LayerNorm + to_q + attention over the (short) context in ONE launch: q never exists in memory
                 w, b, cs = self._w_q_ln(ln)
                 a = ops.xattn(x, w, b, cs, ln.eps, kv[..., :c], kv[..., c:], self.heads, scale=self.scale)
+                if defer_out:
+                    a._vd_deferred_out = True
+                    return a
                 return self.to_out[0](a, res=res, row_sums=out_sums)
             if ln is None:
                 q = self.to_q(x)
@@ -146,9 +161,36 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
 
-    def forward(self, x, context=None, kv=None, qkv=None, ln1_sums=None):
+    def forward(self, x, context=None, kv=None, qkv=None, ln1_sums=None, post=None):
+        """post = (wp [C, C], bp, alpha, res [B, N, C], stat_img_rows): SpatialTransformer.proj_out (+ skip / context mixing) to be
+        folded into the block's last launch.  Returns (tensor, True) when it was -- the tensor is then proj_out's output -- else
+        the block output (the caller runs proj_out)."""
         if hip_layers.LN_FOLD:  # the three LayerNorms ride in the q/k/v, q and GEGLU projections (VD_EPI_LNFOLD)
             x = self.attn1(x, res=x, ln=self.norm1, qkv=qkv, ln_sums=ln1_sums)
+            C = x.shape[-1]
+            fops = self.ff.chain_operands(self.norm3) if (x.is_contiguous() and ops.ff_geglu_supported(C)) else None
+            if fops is not None and (ops.ff_chain_supported(C, "pre") or (post is not None and ops.ff_chain_supported(C, "post"))):
+                # 64x64 level: attn2.to_out + x -> norm3 -> feed-forward -> + x [-> proj_out -> + x_in] in ONE launch
+                w1p, b1p, w2, b2 = fops
+                kw = {}
+                xin = x
+                if ops.ff_chain_supported(C, "pre"):
+                    a = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2, defer_out=True)
+                    if getattr(a, "_vd_deferred_out", False):
+                        wo, bo = self.attn2.to_out[0]._w()
+                        kw.update(a=a, wo=wo, bo=bo)
+                    else:
+                        xin = a   # the projected tensor came back (the unfused cross-attention path)
+                else:
+                    xin = self.attn2(x, context=context, res=x, kv=kv, ln=self.norm2)
+                folded = post is not None and ops.ff_chain_supported(C, "post")
+                if folded:
+                    wp, bp, alpha, pres, hw = post
+                    kw.update(wp=wp, bp=bp, alpha=alpha, res=pres, want_stats=True, stat_img_rows=hw)
+                if kw:
+                    out = ops.ff_chain(xin, w1p, b1p, w2, b2, self.norm3.eps, **kw)
+                    return (out, True) if folded else out
+                return self.ff(xin, res=xin, ln=self.norm3)
             # norm3's statistics: accumulated by attn2's output projection where the feed-forward runs as separate GEMMs (the
             # one-launch feed-forward of the 64x64 level normalises in registers)
             C = x.shape[-1]
@@ -195,8 +237,20 @@ class SpatialTransformer(nn.Module):
             w1, b1 = self.proj_in._w()
             w2, b2, _ = blk.attn1._w_qkv_ln(blk.norm1)
             h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps)
-            h = blk(h, context=context, kv=kv, qkv=qkv)
-            return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)
+            pres = x if res is None else res
+            post = None
+            if pres.is_contiguous() and self.proj_out.out_channels == inner and self.proj_out.bias is not None:
+                wp, bp = self.proj_out._w()
+                post = (wp, bp, float(alpha), pres.view(B, H * W, C), H * W)
+            h = blk(h, context=context, kv=kv, qkv=qkv, post=post)
+            if isinstance(h, tuple):   # proj_out (+ skip, alpha, statistics) ran inside the block's last launch
+                out = h[0]
+                st = ops.stats_of(out)
+                out = out.view(B, H, W, C)
+                if st is not None:
+                    out._vd_stats = st
+                return out
+            return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=pres, want_stats=True)
         # norm1's row statistics ride on proj_in's epilogue (ops.gemm(row_sums=...)) instead of a vd_row_stats_f16 launch
         s1 = ops.rowsum_take(B * H * W, x.device) if hip_layers.LN_FOLD else None
         h = self.proj_in(self.norm(x, silu=False), row_sums=s1)

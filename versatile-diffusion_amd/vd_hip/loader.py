@@ -36,6 +36,15 @@ class VdGemmDesc(ctypes.Structure):
     ]
 
 
+class VdFfChain(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("a", ctypes.c_void_p), ("wo", ctypes.c_void_p), ("bo", ctypes.c_void_p),
+                ("x1_scratch", ctypes.c_void_p), ("w1_packed", ctypes.c_void_p), ("b1_packed", ctypes.c_void_p),
+                ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("bp", ctypes.c_void_p),
+                ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_stats", ctypes.c_void_p),
+                ("M", ctypes.c_int64), ("C", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("alpha", ctypes.c_float),
+                ("reserved", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/vd_hip.h one to one (checked by
 # tests/test_host_cpu.py::test_capi_exports_every_declared_symbol)
 _P, _I, _F, _L, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
@@ -63,6 +72,8 @@ PROTOTYPES = {
     "vd_conv_halo_set_variant": (_I, [_I]),
     "vd_ff_geglu_f16": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "vd_ff_geglu_supported": (_I, [_I]),
+    "vd_ff_chain_f16": (_I, [ctypes.POINTER(VdFfChain), _P]),
+    "vd_ff_chain_supported": (_I, [_I]),
     "vd_gemm_row320_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "vd_gemm_row320_supported": (_I, [_L, _I, _I]),
     "vd_gemm_row320_chain_f16": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),

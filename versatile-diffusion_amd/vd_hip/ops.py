@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-from .loader import VdGemmDesc, VdHipError, lib
+from .loader import VdFfChain, VdGemmDesc, VdHipError, lib
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_BIAS_ALONG_M, EPI_OUT_F32, EPI_LNFOLD, EPI_LN_INLOOP = 1, 2, 4, 8, 16, 32, 64
 EPI_GROUPNORM, EPI_GN_SILU, EPI_LN_SUMS = 128, 256, 512
@@ -621,6 +621,60 @@ def ff_geglu(x, w1_packed, b1_packed, w2, b2, res, ln_eps):
         _check(lib().vd_ff_geglu_f16(_ptr(x), _ptr(w1_packed), _ptr(b1_packed), _ptr(w2), _ptr(b2), _ptr(res), _ptr(y), M, C,
                                      float(ln_eps), _stream()))
     return y
+
+
+# round 5: the C x C projections on either side of the 64x64-level feed-forward in the feed-forward's launch (csrc/ff_chain.hip).
+# VD_FF_CHAIN=0: separate launches; =pre / =post: only that projection is folded (A/B runs)
+FF_CHAIN = os.environ.get("VD_FF_CHAIN", "1")
+
+
+def ff_chain_supported(C, which="both"):
+    """True when vd_ff_chain_f16 is instantiated for inner width C and `which` ('pre' / 'post') is not switched off."""
+    if FF_CHAIN == "0" or not FF_FUSED or (FF_CHAIN in ("pre", "post") and which != FF_CHAIN):
+        return False
+    return bool(lib().vd_ff_chain_supported(int(C)))
+
+
+def ff_chain(x, w1_packed, b1_packed, w2, b2, ln_eps, *, a=None, wo=None, bo=None, wp=None, bp=None, res=None, alpha=1.0,
+             want_stats=False, stat_img_rows=0):
+    """x1 = a wo^T + bo + x (with a);  y = x1 + FF(LayerNorm(x1));  out = alpha (y wp^T + bp) + res (with wp) in one launch
+    (vd_ff_chain_f16, C = 320).  Returns out (or y); with want_stats and wp the per-channel statistics of the stored output
+    ride on it as `_vd_stats` (partials of 128 rows)."""
+    for t, n in ((x, "x"), (w1_packed, "w1"), (b1_packed, "b1"), (w2, "w2"), (b2, "b2"), (a, "a"), (wo, "wo"), (bo, "bo"), (wp, "wp"),
+                 (bp, "bp"), (res, "res")):
+        _req(t, n)
+    C = x.shape[-1]
+    M = x.numel() // C
+    if tuple(w1_packed.shape) != (8 * C, C) or tuple(w2.shape) != (C, 4 * C):
+        raise VdHipError("ff_chain: feed-forward operand shapes do not match C=%d" % C)
+    if a is not None and (a.shape != x.shape or tuple(wo.shape) != (C, C) or bo is None):
+        raise VdHipError("ff_chain: first projection operands do not match x")
+    if wp is not None and (tuple(wp.shape) != (C, C) or bp is None or res is None or res.numel() != x.numel()):
+        raise VdHipError("ff_chain: last projection operands do not match x")
+    d = VdFfChain()
+    d.x, d.w1_packed, d.b1_packed, d.w2, d.b2 = x.data_ptr(), w1_packed.data_ptr(), b1_packed.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    out = torch.empty_like(x)
+    d.out, d.M, d.C, d.ln_eps, d.alpha = out.data_ptr(), int(M), int(C), float(ln_eps), float(alpha)
+    scratch = None
+    if a is not None:
+        scratch = torch.empty_like(x)
+        d.a, d.wo, d.bo, d.x1_scratch = a.data_ptr(), wo.data_ptr(), bo.data_ptr(), scratch.data_ptr()
+    stats = None
+    if wp is not None:
+        d.wp, d.bp, d.res = wp.data_ptr(), bp.data_ptr(), res.data_ptr()
+        hw = int(stat_img_rows) if stat_img_rows else M
+        if want_stats and M % 128 == 0 and hw % 128 == 0:
+            sbuf = torch.empty((M // 128, C, 2), dtype=torch.float32, device=x.device)
+            d.out_stats = sbuf.data_ptr()
+            stats = ChanStats(sbuf, hw // 128, C, hw)
+    nproj = (1 if a is not None else 0) + (1 if wp is not None else 0)
+    flops = 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C + nproj * 2.0 * M * C * C
+    nm = "ff_chain_kernel<%d,%d>" % (int(a is not None), int(wp is not None))
+    with _Timed(nm + ((" M=%d C=%d" % (M, C)) if PROFILE_SHAPES else ""), flops, 2.0 * ((3 + nproj) * M * C + (12 + nproj) * C * C)):
+        _check(lib().vd_ff_chain_f16(ctypes.byref(d), _stream()))
+    if stats is not None:
+        out._vd_stats = stats
+    return out
 
 
 def linear(x, w, bias=None, **kw):
