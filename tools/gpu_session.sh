@@ -10,6 +10,7 @@
 #   ktrace[:ENV=V,...]             rocprofv3 --kernel-trace --stats of 6 eager forwards: per-kernel average durations
 #   trace                          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.csv / breakdown
 #   pmc                            FETCH_SIZE / WRITE_SIZE passes over the forward -> pmc_traffic.json
+#   sq                             two SQ counter passes over 3 eager forwards -> pmc_sq.txt
 #   py:<script and args>           python tools/<script> (commas separate arguments)
 #   rtrace:<script,args>           rocprofv3 --kernel-trace --stats of a tool -> per-kernel averages
 #   rpmc:<CTR+CTR>;<script,args>   one rocprofv3 --pmc pass over a tool -> per-kernel counter means
@@ -74,6 +75,12 @@ for step in "$@"; do
         DB=$(find $O/prof_$n -name "*.db" | head -1)
         python tools/pmc_summary.py $DB > $O/$tag.txt 2> $O/$tag.err; head -60 $O/$tag.txt | cut -c1-160
         rm -rf $O/prof_$n ;;
+    sq)       # two SQ counter passes over 3 eager forwards -> pmc_sq.txt (issue / stall split, matrix-pipe busy, LDS conflicts per kernel)
+        (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES -d $O/sq_a -o a -- python $R/tools/unet_forward.py 3 > $O/sq_a.log 2>&1; echo "sq a rc=$?"
+         timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/sq_b -o b -- python $R/tools/unet_forward.py 3 > $O/sq_b.log 2>&1; echo "sq b rc=$?")
+        A=$(find $O/sq_a -name "*.db" | head -1); B=$(find $O/sq_b -name "*.db" | head -1)
+        python tools/pmc_sq_table.py $A $B > $O/pmc_sq.txt 2> $O/pmc_sq.err; echo "sq table rc=$?"; head -30 $O/pmc_sq.txt | cut -c1-170
+        rm -rf $O/sq_a $O/sq_b ;;
     py)
         timeout 900 python tools/$(echo "$arg" | tr ',' ' ') > $O/$tag.log 2>&1; echo "rc=$?"; tail -25 $O/$tag.log ;;
     *) echo "unknown step $step" ;;

@@ -18,6 +18,9 @@ def norm(name):
         return "%s<%s>" % (m.group(1), ",".join(args))
     if "ff_geglu_kernel" in name:
         return "ff_geglu_kernel"
+    m = re.search(r"ff_chain_kernel<(\w+), (\w+)>", name)
+    if m:
+        return "ff_chain_kernel<%d,%d>" % (m.group(1) == "true", m.group(2) == "true")
     m = re.search(r"(gemm_f16_kernel|attn_fwd_kernel)<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
@@ -25,7 +28,7 @@ def norm(name):
             args = args[:7]   # BM, BN, WM, WN, threads, stages, K depth (the 8th, the occupancy hint, is not part of bench.py's names)
         return "%s<%s>" % (m.group(1), ",".join(args))
     m = re.search(r"(gn_partial_kernel|gn_apply_table_kernel|gn_apply_kernel|gn_slab_kernel|gn_from_stats_kernel|gn_table_kernel|"
-                  r"layernorm_kernel|splitk_reduce_stats_kernel|splitk_reduce_kernel|conv3x3_wstream_kernel|rowchain320_kernel|"
+                  r"layernorm_kernel|splitk_reduce_stats_kernel|splitk_reduce_kernel|conv3x3_wstream_kernel|conv3x3_wsk_kernel|gemm_wstream_kernel|rowchain320_kernel|"
                   r"rowgemm320_kernel|xattn_kernel)", name)
     return m.group(1) if m else None
 
@@ -54,7 +57,8 @@ out = {"library_digest": lib_digest(),   # of the libvd_hip.so the passes ran wi
        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python tools/unet_forward.py 3",
        "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 rocprofv3 reports half of a wide coalesced read "
                "(MI355X_MICROARCH.md, HBM section); counters sit on the L2's fabric side, so Infinity-Cache hits are "
-               "included (upper bound on HBM bytes); WRITE_SIZE uncalibrated",
+               "included (upper bound on HBM bytes); WRITE_SIZE x 1.000 and FETCH_SIZE x 2.04 calibrated on a known 84 MB stream on this "
+               "pool (profiles/r05_pmc_calibration.txt)",
        "kernels": {}}
 for k in sorted(fetch):
     f = sum(fetch[k]) / len(fetch[k])

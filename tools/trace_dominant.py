@@ -2,7 +2,7 @@
 profiles/rNN_trace_dominant.json, stamped with the digest of the library the trace was taken with (bench.py ignores the file
 when another build is loaded).
 
-    python tools/trace_dominant.py <results.db> ["kernel name as bench.py prints it"] > profiles/r04_trace_dominant.json"""
+    python tools/trace_dominant.py <results.db> ["kernel name as bench.py prints it"] > profiles/r05_trace_dominant.json"""
 import json
 import os
 import re
