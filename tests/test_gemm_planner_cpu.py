@@ -302,7 +302,7 @@ def test_which_8x8_convolutions_run_without_a_split_and_which_launches_take_row_
     monkeypatch.delenv("VD_WSK_MIN_BLOCKS", raising=False)
     assert conv8(8, 1280) == 0 and conv8(8, 2560) == 0         # bench shape: 4 image groups x 40 column tiles = 160 blocks
     assert conv8(8, 1280, skip=2560) == 10                      # the folded skip convolution stays on the split kernel
-    assert conv8(4, 1280) == 20                                 # 80 whole-K tiles < 128: 10 split-kernel tiles x 20 one-chunk splits
+    assert conv8(4, 1280) == 20                                 # 80 whole-K tiles < 128: 10 split-kernel tiles, one chunk per split
     assert conv8(8, 1280, split=5) == 5                         # an explicit split factor is honoured
     assert conv8(8, 128) == 2                                   # 2 chunks: below the whole-K kernel's pipeline depth
     assert conv8(8, 1280, flags=128) == 10                      # VD_EPI_GROUPNORM lives in the reduce kernel

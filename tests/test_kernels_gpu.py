@@ -1186,6 +1186,11 @@ def test_conv3x3_wstream(ops, dev, case, monkeypatch):
         o1 = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw1)
         assert rel_l2(o1, ref - kw["rowvec"].float().view(B, 1, 1, Co) + kw["rowvec"][:1].float().view(1, 1, 1, Co)) < 2e-3
     monkeypatch.setenv("VD_WSK", "0")   # the split kernel + reduce launch
+    monkeypatch.setenv("VD_WSTREAM_IPB", "4")   # its 4-images-per-block geometry (opt-in; taken where B % 4 == 0 and N % 128 == 0)
+    out4 = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
+    assert rel_l2(out4, ref) < 2e-3
+    _stats_close(ops.stats_of(out4), _chan_stats_ref(out4.view(B, 64, Co), B, 1), 64)
+    monkeypatch.delenv("VD_WSTREAM_IPB")
     try:
         for var in range(4):
             for target in (256, 64, 1024):

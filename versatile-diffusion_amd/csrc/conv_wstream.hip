@@ -24,10 +24,33 @@ const char* wstream_reject(const VdGemmDesc& d) {
 std::atomic<int> g_ws_variant{-1};   // -1: not read from the environment yet
 std::atomic<int> g_ws_blocks{-1};
 
-template <int D, int OCC>
+template <int D, int OCC, int IPB = 2>
 int launch_wstream(const WsArgs& w, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((conv3x3_wstream_kernel<D, OCC>), dim3(blocks), dim3(256), 2 * WS_HB, stream, w);
+    constexpr int LDS = 2 * 4 * (((IPB * WS_GPX * 128 + 1023) / 1024 + 3) / 4) * 1024;   // two halo buffers
+    if constexpr (LDS > 64 * 1024) {
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wstream_kernel<D, OCC, IPB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) {
+                vd_set_error("vd_conv3x3_wstream_f16: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+                return VD_ERR_LAUNCH;
+            }
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_wstream_kernel<D, OCC, IPB>), dim3(blocks), dim3(256), LDS, stream, w);
     return vd_check_launch("vd_conv3x3_wstream_f16");
+}
+// images per block of the split kernel: 2; opt-in (VD_WSTREAM_IPB=4) 4 -- a wave owns 32 channels over 256 pixels, every weight
+// byte enters half as many CUs.  Built to test whether the launch is bound by what a CU ingests: it is not -- 33.7 vs 32.0 us
+// per launch in isolation, 10.44 / 10.47 vs 10.41 ms per forward (profiles/HISTORY.md, round 5): correct, not faster.
+int wstream_ipb(const VdGemmDesc& d) {
+    const char* env = getenv("VD_WSTREAM_IPB");
+    if (!(env && env[0] == '4')) return 2;
+    return ((d.M / 64) % 4 == 0 && d.N % 128 == 0) ? 4 : 2;
 }
 }  // namespace
 
@@ -97,7 +120,8 @@ extern "C" int vd_conv3x3_wstream_plan(const VdGemmDesc* dp, int* nsplit) {
     const int nchunks = (d.c0 + d.c1) / 64;
     const int nskip = (dp->skip_a0 != nullptr) ? (dp->skip_c0 + (dp->skip_a1 ? dp->skip_c1 : 0)) / 64 : 0;
     if (wsk_takes(d, nchunks, nskip)) { *nsplit = 0; return VD_OK; }
-    *nsplit = wstream_split(d, (d.M / 128) * (d.N / 256), nchunks, nullptr);
+    const int ipb = wstream_ipb(d);
+    *nsplit = wstream_split(d, (d.M / (64 * ipb)) * (d.N / (ipb == 4 ? 128 : 256)), nchunks, nullptr);
     return VD_OK;
 }
 
@@ -129,7 +153,8 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     w.c0 = d.c0; w.c1 = d.c1; w.lda0 = d.lda0; w.lda1 = d.lda1;
     w.nimg = d.M / 64; w.M = d.M; w.N = d.N;
     w.nchunks = (d.c0 + d.c1) / 64;
-    w.tiles_m = w.nimg / 2; w.tiles_n = d.N / 256;
+    const int ipb = wstream_ipb(d);
+    w.tiles_m = w.nimg / ipb; w.tiles_n = d.N / (ipb == 4 ? 128 : 256);
     w.a0_bytes = a.a0_bytes; w.a1_bytes = a.a1_bytes;
     w.s0 = nullptr; w.s1 = nullptr; w.swp = nullptr;
     w.sc0 = w.sc1 = w.slda0 = w.slda1 = w.nskip = w.skip_cps = 0;
@@ -150,6 +175,7 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     if (wsk_takes(d, w.nchunks, w.nskip)) {   // whole K per block, epilogue in the kernel: no slabs, no reduce launch
         WkArgs k;
         k.w = w;
+        k.w.tiles_m = w.nimg / WS_IPB;   // (the whole-K kernel works on image pairs)
         k.w.cps = w.nchunks;
         k.w.nsplit = 1;
         k.w.skip_cps = 0;
@@ -170,7 +196,7 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
             }
             done.fetch_or(bit, std::memory_order_release);
         }
-        hipLaunchKernelGGL(conv3x3_wsk_kernel, dim3(w.tiles_m * (d.N / 32)), dim3(WK_NT), WK_LDS, stream, k);
+        hipLaunchKernelGGL(conv3x3_wsk_kernel, dim3(k.w.tiles_m * (d.N / 32)), dim3(WK_NT), WK_LDS, stream, k);
         return vd_check_launch("vd_conv3x3_wstream_f16/whole-K");
     }
     VD_REQUIRE(d.ws != nullptr, "vd_conv3x3_wstream_f16: needs the split-K workspace (vd_gemm_workspace_bytes)");
@@ -181,11 +207,19 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     w.nsplit = nsplit;
     w.skip_cps = (w.nskip + nsplit - 1) / nsplit;
     int lrc;
-    switch (var) {
-        case 1: lrc = launch_wstream<9, 1>(w, tiles * nsplit, stream); break;
-        case 2: lrc = launch_wstream<4, 2>(w, tiles * nsplit, stream); break;
-        case 3: lrc = launch_wstream<6, 2>(w, tiles * nsplit, stream); break;
-        default: lrc = launch_wstream<12, 1>(w, tiles * nsplit, stream); break;
+    if (ipb == 4) {
+        switch (var) {
+            case 1: lrc = launch_wstream<9, 1, 4>(w, tiles * nsplit, stream); break;
+            case 2: lrc = launch_wstream<12, 1, 4>(w, tiles * nsplit, stream); break;
+            default: lrc = launch_wstream<18, 1, 4>(w, tiles * nsplit, stream); break;
+        }
+    } else {
+        switch (var) {
+            case 1: lrc = launch_wstream<9, 1>(w, tiles * nsplit, stream); break;
+            case 2: lrc = launch_wstream<4, 2>(w, tiles * nsplit, stream); break;
+            case 3: lrc = launch_wstream<6, 2>(w, tiles * nsplit, stream); break;
+            default: lrc = launch_wstream<12, 1>(w, tiles * nsplit, stream); break;
+        }
     }
     if (lrc != VD_OK) return lrc;
     return vd_gemm_launch_reduce(&a, nsplit, stream);

@@ -51,10 +51,22 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
     }
 }
 
-// D = k-steps of weight fragments in flight per wave (divides 36); OCC = waves per SIMD the register budget is set for
-template <int D, int OCC>
+// D = k-steps of weight fragments in flight per wave (divides 36); OCC = waves per SIMD the register budget is set for;
+// IPB = images per block.  IPB = 2 (round 4): 128 pixels, a wave owns 64 output channels (2 n tiles) -> 256 channels per block.
+// IPB = 4 (round 5): 256 pixels, a wave owns 32 output channels (1 n tile) over all eight pixel tiles -> 128 channels per block:
+// the same 8 MFMAs per k-step and wave, but every weight byte now enters HALF as many CUs.  The launch is bound by what a CU
+// ingests through its L1 (~27 GB/s per CU for global -> register loads, measured on the whole-K variant: conv_wsk_kernel.h), and
+// the bench shape's 29.5 MB of weights used to enter 4 CUs each (one per image pair).
+template <int D, int OCC, int IPB = 2>
 __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs p) {
     static_assert(36 % D == 0, "the fragment ring must divide the 36 k-steps of a chunk");
+    static_assert(IPB == 2 || IPB == 4, "image groups of 2 or 4");
+    constexpr int NPX = IPB * 2;                        // 32-pixel tiles of the block (all of them in every wave)
+    constexpr int NTW = 4 / IPB;                        // n tiles (32 channels) per wave
+    constexpr int NPIECE = (IPB * WS_GPX * 128 + 1023) / 1024;
+    constexpr int PPW = (NPIECE + 3) / 4;               // halo pieces per wave and chunk
+    constexpr int HB = 4 * PPW * 1024;                  // bytes of a halo buffer
+    static_assert((36 - PPW) * NTW >= NTW * D, "the halo pieces of a chunk must be older than the fragment ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -72,8 +84,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
     const int rest = bid / p.tiles_m;
     const int tn = rest % p.tiles_n;
     const int split = rest / p.tiles_n;
-    const int img0 = tm * WS_IPB;
-    const int n0 = tn * 256 + wave_s * 64;
+    const int img0 = tm * IPB;
+    const int n0 = tn * (128 * NTW) + wave_s * (32 * NTW);
     const int c_begin = split * p.cps;
     int c_end = c_begin + p.cps;
     if (c_end > p.nchunks) c_end = p.nchunks;
@@ -85,15 +97,15 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
 
     // ---- halo pieces of this wave: piece q = j * 4 + wave covers halo pixels 8q .. 8q + 7, lane = (pixel in piece) * 8 +
     // physical slot; packed (input pixel << 3 | logical slot), -1 = zeros (padding ring, pitch filler, tail)
-    int hsrc[7];
+    int hsrc[PPW];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < PPW; ++j) {
         const int hp = (j * 4 + wave) * 8 + (lane >> 3);
-        const int g = hp >= WS_GPX ? 1 : 0;
+        const int g = hp / WS_GPX;
         const int rem = hp - g * WS_GPX;
         const int yh = (rem * 373) >> 12;        // rem / 11 for rem < 128
         const int xh = rem - yh * WS_PITCH;
-        const bool ok = hp < WS_IPB * WS_GPX && yh >= 1 && yh <= 8 && xh >= 1 && xh <= 8;
+        const bool ok = hp < IPB * WS_GPX && yh >= 1 && yh <= 8 && xh >= 1 && xh <= 8;
         const int pix = ((img0 + g) * 8 + yh - 1) * 8 + xh - 1;
         hsrc[j] = ok ? ((pix << 3) | ((lane & 7) ^ (xh & 7))) : -1;
     }
@@ -114,33 +126,33 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
         dma16(cs.rs, buf_lds + (unsigned)((j * 4 + wave_s) * 1024), voff, cs.soff);
     };
 
-    // ---- weight stream of this wave: two n tiles, 36 fragments (1 KiB each) per chunk and tile, consecutive chunks contiguous
+    // ---- weight stream of this wave: NTW n tiles, 36 fragments (1 KiB each) per chunk and tile, consecutive chunks contiguous
     const int nt0 = n0 >> 5;
     const uint4* wq0 = p.wp + ((size_t)nt0 * p.nchunks + c_begin) * (36 * 64) + lane;
-    const uint4* wq1 = p.wp + ((size_t)(nt0 + 1) * p.nchunks + c_begin) * (36 * 64) + lane;
+    const uint4* wq1 = p.wp + ((size_t)(nt0 + (NTW - 1)) * p.nchunks + c_begin) * (36 * 64) + lane;
     const int kmax = ncl * 36 - 1;
-    U4H8 wf[D][2];
+    U4H8 wf[D][NTW];
     auto load_w = [&](auto rt, int kk) {   // fragments of k-step kk (clamped: the tail re-reads the last one) -> ring slot
         constexpr int r = decltype(rt)::value;
         const int k = kk < kmax ? kk : kmax;
         wf[r][0].u = wq0[(size_t)k * 64];
-        wf[r][1].u = wq1[(size_t)k * 64];
+        if constexpr (NTW == 2) wf[r][1].u = wq1[(size_t)k * 64];
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[NPX][NTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NPX; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // pixel fragments: lane pixel m = i * 32 + l31 of the block's 128 -> image g = m >> 6, (y, x) = ((m >> 3) & 7, m & 7); halo
     // pixel of tap (ky, kx) = g * 110 + (y + ky) * 11 + x + kx, slot key = (x + kx) & 7:
     //   byte = pixel * 128 + ((((2 ks + hi) ^ key)) << 4) = hp0b[i] + (tkx[kx] ^ (ks << 5)) + (ky * 11 + kx) * 128
-    int hp0b[4], tkx[3];   // (m & 7) == (l31 & 7) for every pixel tile: the slot term depends on kx only
+    int hp0b[NPX], tkx[3];   // (m & 7) == (l31 & 7) for every pixel tile: the slot term depends on kx only
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPX; ++i) {
         const int m = i * 32 + l31;
         hp0b[i] = ((m >> 6) * WS_GPX + ((m >> 3) & 7) * WS_PITCH + (m & 7)) * 128;
     }
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
         constexpr int s = decltype(st)::value;
         constexpr int tap = s >> 2, ks = s & 3, ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPX; ++i) {
             U4H8 v;
             v.u = *reinterpret_cast<const uint4*>(smem + buf_off + hp0b[i] + (tkx[kx] ^ (ks << 5)) + (ky * WS_PITCH + kx) * 128);
             b[i] = v.h;
@@ -160,19 +172,19 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
     // ---- prologue: halo of the first chunk, the first D k-steps of weights
     {
         const ChunkSrc cs0 = chunk_src(c_begin);
-        ws_static_for<0, 7>([&](auto jt) { issue_halo(jt, cs0, lds0); });
+        ws_static_for<0, PPW>([&](auto jt) { issue_halo(jt, cs0, lds0); });
     }
     ws_static_for<0, D>([&](auto rt) { load_w(rt, decltype(rt)::value); });
 
-    f16x8 bf[2][4];
+    f16x8 bf[2][NPX];
     for (int lc = 0; lc < ncl; ++lc) {
-        const int buf_off = (lc & 1) * WS_HB;
-        const unsigned nxt_lds = lds0 + (unsigned)(((lc & 1) ^ 1) * WS_HB);
+        const int buf_off = (lc & 1) * HB;
+        const unsigned nxt_lds = lds0 + (unsigned)(((lc & 1) ^ 1) * HB);
         const bool more = lc + 1 < ncl;
         const ChunkSrc csn = chunk_src(more ? c_begin + lc + 1 : c_begin + lc);
         // this chunk's halo pieces (issued during the previous chunk, older than all but the youngest 2 * D weight loads) have
         // landed for this wave ... for every wave; every wave has left the previous chunk, whose buffer the DMA below refills
-        wait_vm<2 * D>();
+        wait_vm<NTW * D>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_b(std::integral_constant<int, 0>{}, buf_off, bf[0]);
@@ -182,13 +194,13 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
             if constexpr (s < 35) read_b(std::integral_constant<int, s + 1>{}, buf_off, bf[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NPX; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NTW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % D][j].h, bf[s & 1][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             load_w(std::integral_constant<int, s % D>{}, kk0 + s + D);
-            if constexpr (s < 7) {
+            if constexpr (s < PPW) {
                 if (more) issue_halo(std::integral_constant<int, s>{}, csn, nxt_lds);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
         const i32x4 rs_s0 = make_rsrc_words(p.s0, p.s0_bytes);
         const i32x4 rs_s1 = make_rsrc_words(p.s1 ? p.s1 : p.s0, p.s1 ? p.s1_bytes : 0u);
         const uint4* sq0 = p.swp + (size_t)nt0 * p.nskip * (4 * 64) + lane;
-        const uint4* sq1 = p.swp + (size_t)(nt0 + 1) * p.nskip * (4 * 64) + lane;
+        const uint4* sq1 = p.swp + (size_t)(nt0 + (NTW - 1)) * p.nskip * (4 * 64) + lane;
         for (int c = s_begin; c < s_end; ++c) {
             wait_vm<0>();
             __builtin_amdgcn_s_barrier();   // every wave has left the buffer the DMA below refills (buffer 0 is re-used)
@@ -218,29 +230,29 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
                 cs.ld2 = (second ? p.slda1 : p.slda0) * 2;
                 cs.soff = (unsigned)((second ? cc - p.sc0 : cc) * 2);
             }
-            ws_static_for<0, 7>([&](auto jt) { issue_halo(jt, cs, lds0); });
-            U4H8 sw[4][2];
+            ws_static_for<0, PPW>([&](auto jt) { issue_halo(jt, cs, lds0); });
+            U4H8 sw[4][NTW];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 sw[ks][0].u = sq0[((size_t)c * 4 + ks) * 64];
-                sw[ks][1].u = sq1[((size_t)c * 4 + ks) * 64];
+                if constexpr (NTW == 2) sw[ks][1].u = sq1[((size_t)c * 4 + ks) * 64];
             }
             wait_vm<0>();
             __builtin_amdgcn_s_barrier();   // the halo has landed for every wave
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                f16x8 b4[4];
+                f16x8 b4[NPX];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NPX; ++i) {
                     U4H8 v;
                     v.u = *reinterpret_cast<const uint4*>(smem + hp0b[i] + (tkx[1] ^ (ks << 5)) + (WS_PITCH + 1) * 128);   // tap (1, 1)
                     b4[i] = v.h;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NPX; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sw[ks][j].h, b4[i], acc[i][j], 0, 0, 0);
             }
         }
@@ -249,10 +261,10 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_wstream_kernel(const WsArgs 
     // ---- fp32 slab of this split for the reduce kernel, straight from registers (4 consecutive floats per lane and group)
     float* base = p.ws + (size_t)split * (size_t)p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPX; ++i) {
         const int row = img0 * 64 + i * 32 + l31;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = n0 + j * 32 + 8 * g + 4 * hi;
