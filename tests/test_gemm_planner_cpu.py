@@ -75,7 +75,10 @@ def test_wide_tile_for_the_64x64_level():
     for K, ks in ((2880, 3), (5760, 3), (1280, 1)):
         assert plan(32768, 320, K, ks=ks, halo=0) == (T128x320, 1)     # one block spans all of N: A is read from L2 once
     assert plan(32768, 320, 320) == (T128x64w8, 1)            # short K, many rows: small tiles, 4 waves per SIMD
-    assert plan(8192, 640, 640) == (T128x64w8, 1)
+    assert plan(8192, 640, 640) == (T128x128w8, 1)            # round 5: N = 640 at M >= 8192 takes the 128x128 tile (in-forward A/B)
+    assert plan(4096, 640, 640) == (T128x64w8, 1)
+    assert plan(2048, 1280, 1280) == (T128x64d, 1)            # 640 blocks of 64x64 -> 320 co-resident 128x64 blocks, three stages
+    assert plan(512, 1280, 1280)[0] == T64x64d                # the 8x8 level keeps its (already deep) 64x64 grid
     assert plan(32768, 960, 320) == (T128x320, 1)             # N > 640: the wide tile
     # 64 tiles of 128x320 would leave 3/4 of the CUs idle
     assert plan(8192, 640, 5760, ks=3, halo=0)[0] not in (T128x320, T128x320q, T128x160q)

@@ -638,8 +638,10 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     } else if (a.kt_total < 20 && d.M >= 4096 && d.N <= 640) {
         // short-K projections of the high-resolution levels (K = 320 .. 1280 against 8192+ rows): output-write bound and
         // short-lived blocks -- 128x64 tiles on 8 waves (4 waves per SIMD, 4+ blocks per CU at different phases) beat the
-        // large tiles by 7-24 % inside a forward
-        cfg = T128x64w8;
+        // large tiles by 7-24 % inside a forward.  Round 5 (re-measured with the repaired epilogues, tools/unet_forward.py with
+        // VD_FWD_TUNE pins, same box): at N = 640 and M >= 8192 the 128x128 tile on 8 waves is 6 us per launch faster than the
+        // 128x64 one (20 launches per forward: 10.605 -> 10.48-10.50 ms); at N = 320 both tiles measure the same
+        cfg = (d.N > 320 && d.M >= 8192) ? T128x128w8 : T128x64w8;
     } else {
         float best = 1e30f;
         const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1);
@@ -721,6 +723,12 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         if (ktps >= 8) {
             if (cfg == T128x64 && grid_blocks <= deep128) cfg = T128x64d;
             else if (cfg == T64x64 && grid_blocks <= deep64) cfg = T64x64d;
+            else if (cfg == T64x64 && nsplit == 1 && ktps >= 16 && d.M % 128 == 0 && grid_blocks / 2 <= deep128 && d.act != VD_ACT_GEGLU) {
+                // round 5: a 64x64 grid too large for the deep ring whose 128x64 grid fits it (M = 2048, N = K = 1280: 640 -> 320
+                // blocks, all co-resident with three stages): 10.166 -> 10.120 ms per forward for the 20 C x C launches of the
+                // 16x16 level (VD_FWD_TUNE pin A/B)
+                cfg = T128x64d;
+            }
         }
     }
     if (lnfold) {
