@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 6
+#define VD_HIP_ABI_VERSION 7
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -132,6 +132,14 @@ typedef struct VdGemmDesc {
      * buffer as ln_stats with VD_EPI_LN_SUMS.  Only unsplit gemm_f16_kernel launches with vector-aligned fp16 output take it:
      * ask vd_gemm_row_sums_ok(desc) first. */
     void* row_sums;
+    /* Per-(image, channel) sums for a consuming GroupNorm (ABI 7), next to out_stats: int64 [images][N][2], ZEROED by the caller.
+     * Every launch that writes an out_stats partial (mean, M2 over R rows of one image) also adds, atomically and in fixed point,
+     * R * mean x 2^32 and (M2 + R * mean^2) x 2^16 (formed in fp64 from the shifted partial) for the image the partial lies in
+     * (row / stat_img_rows), so after the launch stat_sums[img][n] = (sum, sum of squares) over the image's rows of channel n:
+     * ONE pair per (image, channel) whatever the producer's tile shape, which the consumer folds itself (vd_gn_apply_sums_f16:
+     * no vd_gn_table_f32 launch).  Integer adds: the result does not depend on the order the blocks arrive in.  Needs out_stats
+     * and stat_img_rows > 0; launchers that cannot emit out_stats ignore it (the consumer checks the producer's report). */
+    void* stat_sums;
 } VdGemmDesc;
 #define VD_GEMM_SYNC_INTS 16384
 
@@ -281,6 +289,8 @@ typedef struct VdFfChain {
     const void* res;        /* fp16 [M][C]: residual of the last projection */
     void* out;              /* fp16 [M][C] */
     float* out_stats;       /* or NULL */
+    void* stat_sums;        /* or NULL (with out_stats): int64 [M / stat_img_rows][C][2], as VdGemmDesc.stat_sums (ABI 7) */
+    int64_t stat_img_rows;  /* rows of one image (a multiple of 128) for stat_sums */
     int64_t M;
     int32_t C;
     float ln_eps, alpha;
@@ -319,6 +329,13 @@ int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, in
                     const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream);
 int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int apply_silu,
                           void* y, hipStream_t stream);
+/* vd_gn_apply_sums_f16 (ABI 7): y = act(GroupNorm(cat(x0, x1))) from the per-(image, channel) fixed-point sums the producers
+ * accumulated (VdGemmDesc.stat_sums: sums0 int64 [B][c0][2], sums1 int64 [B][c1][2] or NULL): every block folds the sums of its
+ * image into (mean, rstd) per group in fp64 (8 lanes per group, no partial lists), builds scale / shift of its channel octets in
+ * registers and streams its rows once.  groups <= 32.  Replaces the vd_gn_table_f32 + vd_gn_apply_table_f16 pair (same reference
+ * lines as vd_groupnorm_silu_f16). */
+int vd_gn_apply_sums_f16(const void* x0, int c0, const void* sums0, const void* x1, int c1, const void* sums1, int B, int HW,
+                         const void* gamma, const void* beta, int groups, float eps, int apply_silu, void* y, hipStream_t stream);
 /* The same map as fp16 [B][C0 + C1] scale / shift vectors: the gn_scale / gn_shift operands of vd_gemm_row320_chain_f16
  * (what vd_groupnorm_affine_f16 computes with a pass over x). */
 int vd_gn_affine_from_stats_f16(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,

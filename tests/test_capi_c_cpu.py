@@ -40,12 +40,12 @@ int main(int argc, char** argv) {
     d.Hin = d.Win = d.Hout = d.Wout = 16;
     int cfg = -1, ns = -1;
     int rc = plan(&d, &cfg, &ns);
-    printf("abi=%d version_macro=%d sizeof=%zu off_M=%zu off_stride_a=%zu off_colsum=%zu off_sync=%zu off_ln_stats=%zu off_out_stats=%zu off_stat_img_rows=%zu off_gn_gamma=%zu off_gn_eps=%zu off_skip_a0=%zu off_skip_w=%zu off_skip_c0=%zu off_skip_ldw=%zu off_row_sums=%zu\n",
+    printf("abi=%d version_macro=%d sizeof=%zu off_M=%zu off_stride_a=%zu off_colsum=%zu off_sync=%zu off_ln_stats=%zu off_out_stats=%zu off_stat_img_rows=%zu off_gn_gamma=%zu off_gn_eps=%zu off_skip_a0=%zu off_skip_w=%zu off_skip_c0=%zu off_skip_ldw=%zu off_row_sums=%zu off_stat_sums=%zu\n",
            abi(), VD_HIP_ABI_VERSION, sizeof(VdGemmDesc), offsetof(VdGemmDesc, M), offsetof(VdGemmDesc, stride_a),
            offsetof(VdGemmDesc, colsum), offsetof(VdGemmDesc, sync), offsetof(VdGemmDesc, ln_stats),
            offsetof(VdGemmDesc, out_stats), offsetof(VdGemmDesc, stat_img_rows), offsetof(VdGemmDesc, gn_gamma),
            offsetof(VdGemmDesc, gn_eps), offsetof(VdGemmDesc, skip_a0), offsetof(VdGemmDesc, skip_w),
-           offsetof(VdGemmDesc, skip_c0), offsetof(VdGemmDesc, skip_ldw), offsetof(VdGemmDesc, row_sums));
+           offsetof(VdGemmDesc, skip_c0), offsetof(VdGemmDesc, skip_ldw), offsetof(VdGemmDesc, row_sums), offsetof(VdGemmDesc, stat_sums));
     printf("plan rc=%d cfg=%d ns=%d name=%s ws=%zu\n", rc, cfg, ns, name(cfg), ws(&d));
     d.K = 12;   /* not a multiple of 8: rejected with a message, no device touched */
     rc = plan(&d, &cfg, &ns);
@@ -67,12 +67,12 @@ def test_header_compiles_as_plain_c_and_layout_matches_ctypes(tmp_path):
     assert run.returncode == 0, run.stderr
     lines = run.stdout.strip().splitlines()
     kv = dict(t.split("=") for t in lines[0].split())
-    assert int(kv["abi"]) == int(kv["version_macro"]) == 6
+    assert int(kv["abi"]) == int(kv["version_macro"]) == 7
     assert int(kv["sizeof"]) == ctypes.sizeof(VdGemmDesc)
     for field, key in (("M", "off_M"), ("stride_a", "off_stride_a"), ("colsum", "off_colsum"), ("sync", "off_sync"), ("ln_stats", "off_ln_stats"),
                        ("out_stats", "off_out_stats"), ("stat_img_rows", "off_stat_img_rows"), ("gn_gamma", "off_gn_gamma"),
                        ("gn_eps", "off_gn_eps"), ("skip_a0", "off_skip_a0"), ("skip_w", "off_skip_w"), ("skip_c0", "off_skip_c0"),
-                       ("skip_ldw", "off_skip_ldw"), ("row_sums", "off_row_sums")):
+                       ("skip_ldw", "off_skip_ldw"), ("row_sums", "off_row_sums"), ("stat_sums", "off_stat_sums")):
         assert int(kv[key]) == getattr(VdGemmDesc, field).offset, field
     # same plan as the ctypes path (tests/test_gemm_planner_cpu.py): the 16x16-level 3x3 conv runs on the halo kernel, 4-way split
     assert lines[1].startswith("plan rc=0 cfg=29 ns=4 name=conv3x3_halo_kernel<256,160,32,160,512,2>")

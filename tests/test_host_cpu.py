@@ -24,7 +24,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(PROTOTYPES), (declared ^ set(PROTOTYPES))
     for name in declared:
         assert hasattr(h, name), name
-    assert h.vd_abi_version() == 6
+    assert h.vd_abi_version() == 7
     # argument validation works without a device
     from vd_hip.loader import VdGemmDesc
     d = VdGemmDesc()
@@ -35,7 +35,7 @@ def test_capi_exports_every_declared_symbol():
 
 def test_gemm_desc_struct_matches_header():
     from vd_hip.loader import VdGemmDesc
-    skip = 3 * 8 + 6 * 4 + 8   # folded skip convolution (ABI 5): three pointers, five ints + one reserved; row_sums (ABI 6)
+    skip = 3 * 8 + 6 * 4 + 8 + 8   # folded skip convolution (ABI 5): three pointers, five ints + one reserved; row_sums (ABI 6); stat_sums (ABI 7)
     assert ctypes.sizeof(VdGemmDesc) == 8 * 8 + 24 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + skip
     assert VdGemmDesc.stride_a.offset == 8 * 8 + 24 * 4
     assert VdGemmDesc.colsum.offset == 8 * 8 + 24 * 4 + 4 * 8   # LayerNorm-fold fields (ABI 2)
@@ -44,8 +44,9 @@ def test_gemm_desc_struct_matches_header():
     assert VdGemmDesc.out_stats.offset == ctypes.sizeof(VdGemmDesc) - 40 - skip   # producer-emitted GroupNorm statistics (ABI 5)
     assert VdGemmDesc.gn_gamma.offset == ctypes.sizeof(VdGemmDesc) - 24 - skip    # GroupNorm fused into the split-K reduce (ABI 5)
     assert VdGemmDesc.skip_a0.offset == ctypes.sizeof(VdGemmDesc) - skip
-    assert VdGemmDesc.skip_c0.offset == ctypes.sizeof(VdGemmDesc) - 6 * 4 - 8
-    assert VdGemmDesc.row_sums.offset == ctypes.sizeof(VdGemmDesc) - 8   # producer-accumulated LayerNorm row sums (ABI 6)
+    assert VdGemmDesc.skip_c0.offset == ctypes.sizeof(VdGemmDesc) - 6 * 4 - 16
+    assert VdGemmDesc.row_sums.offset == ctypes.sizeof(VdGemmDesc) - 16   # producer-accumulated LayerNorm row sums (ABI 6)
+    assert VdGemmDesc.stat_sums.offset == ctypes.sizeof(VdGemmDesc) - 8   # producer-accumulated GroupNorm sums (ABI 7)
 
 
 def test_model_cfg_bank_resolves_four_flow():

@@ -267,6 +267,11 @@ def test_ff_chain(ops, dev, M, pre, post, offset):
     if post and M % 128 == 0:
         assert st is not None and st.T == M // 128 and st.HW == M
         _stats_close(st, _chan_stats_ref(out.view(1, M, C), 1, M // 128), 128)
+        assert (st.sums is not None) == (2 * M * C > ops.GN_FUSED_MAX)   # one pair per (sample, channel) for the table-free apply
+        if st.sums is not None:
+            o64 = out.double()
+            assert torch.allclose(st.sums.view(C, 2)[:, 0].double() / 2.0 ** 32, o64.sum(0), rtol=1e-5, atol=1e-2)
+            assert torch.allclose(st.sums.view(C, 2)[:, 1].double() / 2.0 ** 16, (o64 * o64).sum(0), rtol=1e-5, atol=1e-2)
     else:
         assert st is None
 
@@ -1080,6 +1085,36 @@ def test_gn_fused_large_mean_small_spread(ops, dev, HW, C, R):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("B,HW,c0,c1,mean,sigma", [(2, 4096, 320, 0, 0.0, 1.0), (2, 1024, 640, 320, 0.0, 1.0), (2, 4096, 320, 0, 16.0, 0.03),
+                                                  (3, 1024, 1280, 640, -40.0, 0.05), (1, 9216, 320, 320, 3.0, 2.0)])
+def test_gn_apply_sums(ops, dev, B, HW, c0, c1, mean, sigma):
+    """vd_gn_apply_sums_f16 against torch's GroupNorm: the per-(sample, channel) sums are accumulated here the way the producers
+    do it (partials of chan_stats -> fixed point in fp64), over a skip concat, and with |mean| >> sigma at eps = 1e-6."""
+    g = torch.Generator().manual_seed(410 + HW + c1)
+    mk = lambda c: (mean + sigma * torch.randn((B, HW, c), generator=g)).half().to(dev)
+    x, x1 = mk(c0), (mk(c1) if c1 else None)
+
+    def sums_of(t):
+        st = ops.chan_stats(t, 128)   # (mean, M2) over blocks of 128 rows
+        R = HW // st.T
+        m = st.buf[..., 0].double().view(B, st.T, -1)
+        m2 = st.buf[..., 1].double().view(B, st.T, -1)
+        s = (R * m * 2.0 ** 32).round().long().sum(1)
+        q = ((m2 + R * m * m) * 2.0 ** 16).round().long().sum(1)
+        return torch.stack([s, q], -1).view(-1, 2).contiguous()
+
+    C = c0 + c1
+    gamma = rnd((C,), dev, 0.5, 411) + 1.0
+    beta = rnd((C,), dev, 0.5, 412)
+    cat = torch.cat([x, x1], -1) if c1 else x
+    eps = 1e-6 if sigma < 0.1 else 1e-5
+    ref = F.silu(F.group_norm(cat.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), eps).permute(0, 2, 1))
+    got = ops.gn_apply_sums(x, sums_of(x), gamma, beta, x1=x1, sums1=sums_of(x1) if c1 else None, groups=32, eps=eps, silu=True)
+    assert rel_l2(got, ref) < 3e-3
+    with pytest.raises(ops.VdHipError):
+        ops.gn_apply_sums(x, sums_of(x)[:-1], gamma, beta, x1=x1, sums1=sums_of(x1) if c1 else None)
+
+
 @pytest.mark.parametrize("case", [
     # B, H, W, c0, c1, Co, ksize, stride, ups, rowvec, residual
     (8, 64, 64, 320, 0, 320, 3, 1, 0, True, False),     # halo conv, one block per patch, epilogue statistics
@@ -1135,6 +1170,17 @@ def test_gemm_out_stats(ops, dev, case):
     refn = F.silu(F.group_norm(o3.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
     got = ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True)
     assert rel_l2(got, refn) < 2e-3
+    # tensors large enough for the table + apply pair also carry ONE fixed-point (sum, sum of squares) per (sample, channel)
+    # (VdGemmDesc.stat_sums): exact up to the fp32 rounding of the partials, and the apply launch that folds them itself agrees
+    assert (st.sums is not None) == (ops.GN_SUMS and 2 * B * Ho * Wo * Co > ops.GN_FUSED_MAX)
+    if st.sums is not None:
+        sm = st.sums.view(B, Co, 2).double()
+        o64 = o3.double()
+        assert torch.allclose(sm[..., 0] / 2.0 ** 32, o64.sum(1), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(sm[..., 1] / 2.0 ** 16, (o64 * o64).sum(1), rtol=1e-5, atol=1e-2)
+        got = ops.gn_apply_sums(o3, st.sums, gamma, beta, groups=32, eps=1e-5, silu=True)
+        assert rel_l2(got, refn) < 2e-3
+        assert torch.equal(ops.groupnorm_silu(o3, gamma, beta, groups=32, eps=1e-5, silu=True), got)   # the path the model takes
 
 
 @pytest.mark.parametrize("case", [

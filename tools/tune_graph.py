@@ -74,6 +74,7 @@ def main():
     install(pins)
     if not args.problems:   # the GEMM problems of this forward, by device time (per-launch events of one eager forward)
         fwd(); torch.cuda.synchronize()
+        ops.PROFILE_SHAPES = True
         ops.profile_begin()
         fwd()
         tm = {}
@@ -83,6 +84,7 @@ def main():
                 key = (int(f["M"]), int(f["N"]), int(f["K"]), int(f["ks"]), int(f["cls"]))
                 tm[key] = tm.get(key, 0.0) + ms
         problems = [k for k, v in sorted(tm.items(), key=lambda kv: -kv[1]) if k[0] >= 96 and k[1] >= 96 and k[3] == 1][:args.top]
+        ops.PROFILE_SHAPES = False
         for k in problems:
             print("problem M=%d N=%d K=%d ks=%d cls=%d: %.3f ms per forward (eager events)" % (k + (tm[k],)))
     base, ref = measure()

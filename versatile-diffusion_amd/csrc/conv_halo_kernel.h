@@ -811,7 +811,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         __syncthreads();
         const int nsub = p.ngrp, R = BM / p.ngrp;
         emit_chan_stats<BN, CS_LD, NT>(cs, reinterpret_cast<float*>(smem + BM * CS_LD * 2), tid, R, nsub, nsub, d.out_stats,
-                                       (size_t)tm * nsub, d.N, n0);
+                                       (size_t)tm * nsub, d.N, n0, reinterpret_cast<unsigned long long*>(d.stat_sums), d.stat_img_rows);
     }
     VD_TL(4);   // (behind the statistics pass where one runs)
     VD_TL_FLUSH(p.g.tl);

@@ -127,6 +127,7 @@ extern "C" int vd_conv3x3_wstream_plan(const VdGemmDesc* dp, int* nsplit) {
 
 extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
     VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_conv3x3_wstream_f16: null argument");
+    VD_REQUIRE(dp->stat_sums == nullptr, "vd_conv3x3_wstream_f16: stat_sums is taken by vd_gemm_f16 / vd_ff_chain_f16 only");
     VdGemmDesc tmp = *dp;
     tmp.w = w_stream;          // the K-contiguous weights are not read on this path
     tmp.out_stats = nullptr;   // (validated below, not by the planner of the other kernels)
@@ -269,6 +270,7 @@ extern "C" int vd_gemm_wstream_plan(const VdGemmDesc* dp, int* nsplit) {
 
 extern "C" int vd_gemm_wstream_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
     VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_gemm_wstream_f16: null argument");
+    VD_REQUIRE(dp->stat_sums == nullptr, "vd_gemm_wstream_f16: stat_sums is taken by vd_gemm_f16 / vd_ff_chain_f16 only");
     VdGemmDesc tmp = *dp;
     tmp.w = w_stream;          // the K-contiguous weights are not read on this path
     tmp.out_stats = nullptr;   // (validated below, not by the planner of the other kernels)
@@ -437,6 +439,7 @@ extern "C" int vd_conv3x3_wreg_plan(const VdGemmDesc* dp, int* supported, int* n
 
 extern "C" int vd_conv3x3_wreg_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
     VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_conv3x3_wreg_f16: null argument");
+    VD_REQUIRE(dp->stat_sums == nullptr, "vd_conv3x3_wreg_f16: stat_sums is taken by vd_gemm_f16 / vd_ff_chain_f16 only");
     VD_REQUIRE(((size_t)w_stream & 15) == 0, "vd_conv3x3_wreg_f16: w_stream must be 16-byte aligned");
     GemmArgs a;
     WrArgs w;

@@ -55,6 +55,8 @@ struct FCArgs {
     const f16* r;      // POST: [M][C] residual of the last projection
     f16* y;            // [M][C] output (POST: out, else y)
     float* out_stats;  // POST: fp32 [M / 128][C][2] per-channel (mean, M2) of the stored rows, or null
+    unsigned long long* stat_sums;   // POST, with out_stats: int64 [M / img_rows][C][2] fixed-point sums (VdGemmDesc.stat_sums), or null
+    int img_rows;
     int M;
     float eps, alpha;
     int nt_store;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
             __syncthreads();
             const int left = (p.M - m0) / FC_BM;
             emit_chan_stats<FC_C, FC_CS_LD, 512>(cs, reinterpret_cast<float*>(smem + FC_RING), tid, FC_BM, 1, left < 1 ? left : 1, p.out_stats,
-                                                 (size_t)(m0 / FC_BM), FC_C, 0);
+                                                 (size_t)(m0 / FC_BM), FC_C, 0, p.stat_sums, p.img_rows);
         }
     }
 }
@@ -459,6 +461,9 @@ extern "C" int vd_ff_chain_f16(const VdFfChain* c, hipStream_t stream) {
     if (post) VD_REQUIRE(c->bp && c->res, "vd_ff_chain_f16: the last projection needs bp and its residual");
     VD_REQUIRE(post || c->out_stats == nullptr, "vd_ff_chain_f16: out_stats describe the last projection's output");
     VD_REQUIRE(c->out_stats == nullptr || c->M % FC_BM == 0, "vd_ff_chain_f16: out_stats need M %% 128 == 0");
+    VD_REQUIRE(c->stat_sums == nullptr || (c->out_stats != nullptr && ((size_t)c->stat_sums & 7) == 0 && c->stat_img_rows > 0 &&
+                                           c->stat_img_rows % FC_BM == 0 && c->M % c->stat_img_rows == 0),
+               "vd_ff_chain_f16: stat_sums rides on out_stats (whole images of stat_img_rows rows, a multiple of 128)");
     const size_t align16 = (size_t)c->x | (size_t)c->w1_packed | (size_t)c->w2 | (size_t)c->out | (size_t)c->a | (size_t)c->wo | (size_t)c->x1_scratch |
                            (size_t)c->wp | (size_t)c->res;
     const size_t align8 = (size_t)c->b1_packed | (size_t)c->b2 | (size_t)c->bo | (size_t)c->bp | (size_t)c->out_stats;
@@ -467,6 +472,7 @@ extern "C" int vd_ff_chain_f16(const VdFfChain* c, hipStream_t stream) {
     a.x = (const f16*)c->x; a.a = (const f16*)c->a; a.wo = (const f16*)c->wo; a.bo = (const f16*)c->bo; a.x1 = (f16*)c->x1_scratch;
     a.w1 = (const f16*)c->w1_packed; a.b1 = (const f16*)c->b1_packed; a.w2 = (const f16*)c->w2; a.b2 = (const f16*)c->b2;
     a.wp = (const f16*)c->wp; a.bp = (const f16*)c->bp; a.r = (const f16*)c->res; a.y = (f16*)c->out; a.out_stats = c->out_stats;
+    a.stat_sums = reinterpret_cast<unsigned long long*>(c->stat_sums); a.img_rows = (int)c->stat_img_rows;
     a.M = (int)c->M; a.eps = c->ln_eps; a.alpha = c->alpha;
     static const char* nt_env = getenv("VD_GEMM_NT");
     a.nt_store = nt_env ? (nt_env[0] != '0') : 1;

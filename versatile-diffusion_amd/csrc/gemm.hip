@@ -180,8 +180,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
             S += red[l][tid][0];
             Q += red[l][tid][1];
         }
-        reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * COLS + tid] =
-            make_float2(pivot[tid] + S / 64.f, fmaxf(Q - S * S / 64.f, 0.f));
+        const float mean = pivot[tid] + S / 64.f, m2 = fmaxf(Q - S * S / 64.f, 0.f);
+        reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * COLS + tid] = make_float2(mean, m2);
+        if (d.stat_sums != nullptr)
+            gn_sums_add(reinterpret_cast<unsigned long long*>(d.stat_sums), ((size_t)blockIdx.y * 64) / (size_t)d.stat_img_rows, d.N,
+                        blockIdx.x * COLS + tid, mean, m2, 64);
     }
 }
 
@@ -651,6 +654,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
                 const float t = model_us(c, ns);
                 if (t < best) { best = t; cfg = c.cfg; nsplit = ns; }
             }
+        // the same N = 640 rows with a deep K (FF-out of the 32x32 level, K = 2560): 8 waves on the 128x128 tile, 0.02-0.04 ms
+        // per forward over the 4-wave one (tools/tune_graph.py, two sessions)
+        if (cfg == T128x128 && nsplit == 1 && d.ksize <= 1 && d.N > 320 && d.N <= 640 && d.M >= 8192) cfg = T128x128w8;
     }
     bool tuned = false;
     {   // also with a caller-fixed split (ops.gemm plans first, then launches with split_k = the planned factor): the tuned
@@ -880,6 +886,8 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         return VD_ERR_UNSUPPORTED;
     }
     VD_REQUIRE(((size_t)d.out_stats & 7) == 0, "vd_gemm_f16: out_stats must be 8-byte aligned");
+    VD_REQUIRE(d.stat_sums == nullptr || (d.out_stats != nullptr && ((size_t)d.stat_sums & 7) == 0 && d.stat_img_rows > 0 && d.M % d.stat_img_rows == 0),
+               "vd_gemm_f16: stat_sums rides on out_stats (8-byte aligned, whole images of stat_img_rows rows)");
     if (d.row_sums != nullptr && !row_sums_ok(a, cfg, nsplit)) {
         vd_set_error("vd_gemm_f16: row_sums requested but the planned launch cannot accumulate them (vd_gemm_row_sums_ok)");
         return VD_ERR_UNSUPPORTED;

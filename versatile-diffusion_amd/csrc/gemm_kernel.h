@@ -262,9 +262,19 @@ __device__ __forceinline__ void epi8_finish(const EpiCtx& e, int row, int col, f
 constexpr int stat_lanes(int bn) { return 256 / (bn / 8) < 32 ? 256 / (bn / 8) : 32; }
 constexpr int stat_lds_bytes(int bm, int bn) { return bm * (bn + 8) * 2 + stat_lanes(bn) * bn * 8; }
 
+// VdGemmDesc.stat_sums (ABI 7): the partial (mean, M2 over R rows) of channel n of image img as fixed-point (sum, sum of squares)
+// added to sums[img][n]; the products are formed in fp64 so that the shifted partial loses nothing on the way
+constexpr double GN_SUM_SCALE = 4294967296.0, GN_SQ_SCALE = 65536.0;   // 2^32, 2^16: |sum| < 2^30, sum of squares < 2^46 per image
+__device__ __forceinline__ void gn_sums_add(unsigned long long* sums, size_t img, int N, int n, float mean, float m2, int R) {
+    const double m = (double)mean, r = (double)R;
+    unsigned long long* p = sums + (img * (size_t)N + n) * 2;
+    atomicAdd(p, (unsigned long long)__double2ll_rn(r * m * GN_SUM_SCALE));
+    atomicAdd(p + 1, (unsigned long long)__double2ll_rn((fma(r * m, m, (double)m2)) * GN_SQ_SCALE));
+}
+
 template <int BN, int CS_LD, int NT>
 __device__ __forceinline__ void emit_chan_stats(const f16* cs, float* red, int tid, int R, int nsub, int pvalid, float* out,
-                                                size_t pbase, int N, int n0) {
+                                                size_t pbase, int N, int n0, unsigned long long* sums = nullptr, int img_rows = 0) {
     constexpr int OCT = BN / 8;
     constexpr int LANES = stat_lanes(BN);
     const int co = tid % OCT, rl = tid / OCT;
@@ -302,8 +312,9 @@ __device__ __forceinline__ void emit_chan_stats(const f16* cs, float* red, int t
                         Q += v.y;
                     }
                     const float n = (float)R;
-                    *reinterpret_cast<float2*>(out + ((pbase + s) * (size_t)N + n0 + c) * 2) =
-                        make_float2((float)base[c] + S / n, fmaxf(Q - S * S / n, 0.f));
+                    const float mean = (float)base[c] + S / n, m2 = fmaxf(Q - S * S / n, 0.f);
+                    *reinterpret_cast<float2*>(out + ((pbase + s) * (size_t)N + n0 + c) * 2) = make_float2(mean, m2);
+                    if (sums != nullptr) gn_sums_add(sums, ((pbase + s) * (size_t)R) / (size_t)img_rows, N, n0 + c, mean, m2, R);
                 }
             }
         }
@@ -1258,7 +1269,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             const int R = p.stat_rows, nsub = BM / R;
             const int left = (d.M - m0) / R;   // partials of this tile that lie inside the matrix
             emit_chan_stats<BN, CS_LD, NT>(cs, reinterpret_cast<float*>(smem + BM * CS_LD * 2), tid, R, nsub, left < nsub ? left : nsub,
-                                           d.out_stats, (size_t)(m0 / R), d.N, n0);
+                                           d.out_stats, (size_t)(m0 / R), d.N, n0, reinterpret_cast<unsigned long long*>(d.stat_sums), d.stat_img_rows);
         }
     }
     VD_TL(4);   // output stores issued (the flush waits for them: stamp 6 = stores acknowledged)

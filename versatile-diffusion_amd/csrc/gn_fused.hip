@@ -189,12 +189,47 @@ __global__ __launch_bounds__(64) void gn_table_kernel(const GnTableArgs a) {
 struct GnApplyArgs {
     const f16* x0; const f16* x1; const float* table; f16* out;
     int c0, c1, HW, TC, R, npos, rows_per_chunk, silu;
+    // SUMS: the map is built here from the producers' per-(image, channel) fixed-point sums (VdGemmDesc.stat_sums, ABI 7)
+    const long long* sums0; const long long* sums1; const f16* gamma; const f16* beta;
+    int groups; float eps;
 };
 
+// SUMS = true: no table -- 8 lanes per group add the group's channel sums of this image (int64 -> fp64: exact integers, one
+// rounding at the end), (mean, rstd) of the 32 groups meet in LDS, a thread then forms scale / shift of its octets in registers
+template <bool SUMS>
 __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a) {
+    __shared__ float gstat[32][2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C = a.c0 + a.c1, C8 = C / 8;
     const int tc = tid % a.TC, rl = tid / a.TC;
+    const int cg = SUMS ? C / a.groups : 1;
+    if constexpr (SUMS) {
+        const int g = tid >> 3, sub = tid & 7;
+        double s = 0.0, q = 0.0;
+        if (g < a.groups) {
+#pragma unroll 4
+            for (int i = sub; i < cg; i += 8) {
+                const int ch = g * cg + i;
+                const long long* p = ch < a.c0 ? a.sums0 + ((size_t)b * a.c0 + ch) * 2 : a.sums1 + ((size_t)b * a.c1 + (ch - a.c0)) * 2;
+                const longlong2 v = *reinterpret_cast<const longlong2*>(p);
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (sub == 0 && g < a.groups) {
+            const double n = (double)a.HW * (double)cg;
+            const double mean = s / (4294967296.0 * n);
+            const double var = fmax(q / (65536.0 * n) - mean * mean, 0.0);
+            gstat[g][0] = (float)mean;
+            gstat[g][1] = rsqrtf((float)var + a.eps);
+        }
+        __syncthreads();
+    }
     if (rl >= a.R) return;
     const int r0 = blockIdx.x * a.rows_per_chunk;
     int r1 = r0 + a.rows_per_chunk;
@@ -204,11 +239,24 @@ __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a
         const int cc = tc + pos * a.TC;
         if (cc >= C8) break;
         const int ch = cc * 8;
-        const float* tb = a.table + ((size_t)b * 2) * C + ch;
-        const float4 s0 = *reinterpret_cast<const float4*>(tb), s1 = *reinterpret_cast<const float4*>(tb + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(tb + C), h1 = *reinterpret_cast<const float4*>(tb + C + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        float sc[8], sf[8];
+        if constexpr (SUMS) {
+            U4H8 gm, bt;
+            gm.u = *reinterpret_cast<const uint4*>(a.gamma + ch);
+            bt.u = *reinterpret_cast<const uint4*>(a.beta + ch);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int g = (ch + q) / cg;
+                sc[q] = gstat[g][1] * (float)gm.e[q];
+                sf[q] = (float)bt.e[q] - gstat[g][0] * sc[q];
+            }
+        } else {
+            const float* tb = a.table + ((size_t)b * 2) * C + ch;
+            const float4 s0 = *reinterpret_cast<const float4*>(tb), s1 = *reinterpret_cast<const float4*>(tb + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(tb + C), h1 = *reinterpret_cast<const float4*>(tb + C + 4);
+            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+            sf[0] = h0.x; sf[1] = h0.y; sf[2] = h0.z; sf[3] = h0.w; sf[4] = h1.x; sf[5] = h1.y; sf[6] = h1.z; sf[7] = h1.w;
+        }
         const bool second = ch >= a.c0;
         const f16* src = second ? a.x1 + (ch - a.c0) : a.x0 + ch;
         const int ld = second ? a.c1 : a.c0;
@@ -441,15 +489,38 @@ static int gn_table_launch(const float* stats0, int T0, int c0, const float* sta
     return vd_check_launch("vd_gn_table_f32");
 }
 
+static int gn_apply_launch(const char* who, GnApplyArgs& a, const void* x0, int c0, const void* x1, int c1, int B, int HW, int silu, void* out,
+                           hipStream_t stream);
+
 extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B, int HW, const float* table, int silu,
                                      void* out, hipStream_t stream) {
     VD_REQUIRE(x0 && table && out, "vd_gn_apply_table_f16: null pointer");
-    if (!x1) c1 = 0;
-    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "vd_gn_apply_table_f16: channel counts must be multiples of 8");
-    const int C = c0 + c1, C8 = C / 8;
-    VD_REQUIRE(C8 <= 512, "vd_gn_apply_table_f16: C=%d > 4096", C);
     GnApplyArgs a;
-    a.x0 = reinterpret_cast<const f16*>(x0); a.x1 = reinterpret_cast<const f16*>(x1); a.table = table; a.out = reinterpret_cast<f16*>(out);
+    a.table = table;
+    a.sums0 = a.sums1 = nullptr; a.gamma = a.beta = nullptr; a.groups = 0; a.eps = 0.f;
+    return gn_apply_launch("vd_gn_apply_table_f16", a, x0, c0, x1, c1, B, HW, silu, out, stream);
+}
+
+extern "C" int vd_gn_apply_sums_f16(const void* x0, int c0, const void* sums0, const void* x1, int c1, const void* sums1, int B, int HW,
+                                    const void* gamma, const void* beta, int groups, float eps, int silu, void* out, hipStream_t stream) {
+    VD_REQUIRE(x0 && sums0 && gamma && beta && out && (!x1 || sums1), "vd_gn_apply_sums_f16: null pointer");
+    if (!x1) c1 = 0;
+    VD_REQUIRE(groups > 0 && groups <= 32 && c0 > 0 && c1 >= 0 && (c0 + c1) % groups == 0, "vd_gn_apply_sums_f16: C=%d must divide into at most 32 groups (groups=%d)", c0 + c1, groups);
+    VD_REQUIRE((((size_t)sums0 | (size_t)sums1 | (size_t)gamma | (size_t)beta) & 15) == 0, "vd_gn_apply_sums_f16: sums / gamma / beta must be 16-byte aligned");
+    GnApplyArgs a;
+    a.table = nullptr;
+    a.sums0 = reinterpret_cast<const long long*>(sums0); a.sums1 = reinterpret_cast<const long long*>(sums1);
+    a.gamma = reinterpret_cast<const f16*>(gamma); a.beta = reinterpret_cast<const f16*>(beta); a.groups = groups; a.eps = eps;
+    return gn_apply_launch("vd_gn_apply_sums_f16", a, x0, c0, x1, c1, B, HW, silu, out, stream);
+}
+
+static int gn_apply_launch(const char* who, GnApplyArgs& a, const void* x0, int c0, const void* x1, int c1, int B, int HW, int silu, void* out,
+                           hipStream_t stream) {
+    if (!x1) c1 = 0;
+    VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && c0 > 0 && c0 % 8 == 0 && c1 % 8 == 0, "%s: channel counts must be multiples of 8", who);
+    const int C = c0 + c1, C8 = C / 8;
+    VD_REQUIRE(C8 <= 512, "%s: C=%d > 4096", who, C);
+    a.x0 = reinterpret_cast<const f16*>(x0); a.x1 = reinterpret_cast<const f16*>(x1); a.out = reinterpret_cast<f16*>(out);
     a.c0 = c0; a.c1 = c1; a.HW = HW; a.silu = silu;
     a.TC = C8 < 256 ? C8 : 256;
     a.R = 256 / a.TC;
@@ -457,11 +528,14 @@ extern "C" int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int
     // ~16K elements per block (the optimum the round-3 apply kernel measured), whole row-lane trips
     static const char* chunk_env = getenv("VD_GN_CHUNK");   // development switch: elements per block
     static const int chunk = chunk_env ? atoi(chunk_env) : 8192;   // 8192: measured best with the light prologue (16384: +0.02 ms, 32768: +0.12)
-    int rpc = chunk / C;
+    static const char* schunk_env = getenv("VD_GN_SUMS_CHUNK");   // the same for the form that folds the producers' sums in its prologue
+    static const int schunk = schunk_env ? atoi(schunk_env) : 8192;
+    int rpc = (a.table ? chunk : schunk) / C;
     if (rpc < 1) rpc = 1;
     rpc = ((rpc + a.R - 1) / a.R) * a.R;
     if (rpc > HW) rpc = HW;
     a.rows_per_chunk = rpc;
-    hipLaunchKernelGGL(gn_apply_table_kernel, dim3((HW + rpc - 1) / rpc, B), dim3(256), 0, stream, a);
-    return vd_check_launch("vd_gn_apply_table_f16");
+    if (a.table) hipLaunchKernelGGL(gn_apply_table_kernel<false>, dim3((HW + rpc - 1) / rpc, B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gn_apply_table_kernel<true>, dim3((HW + rpc - 1) / rpc, B), dim3(256), 0, stream, a);
+    return vd_check_launch(who);
 }

@@ -33,6 +33,7 @@ class VdGemmDesc(ctypes.Structure):
         ("skip_c0", ctypes.c_int32), ("skip_c1", ctypes.c_int32), ("skip_lda0", ctypes.c_int32), ("skip_lda1", ctypes.c_int32),
         ("skip_ldw", ctypes.c_int32), ("reserved4", ctypes.c_int32),
         ("row_sums", ctypes.c_void_p),
+        ("stat_sums", ctypes.c_void_p),
     ]
 
 
@@ -41,6 +42,7 @@ class VdFfChain(ctypes.Structure):
                 ("x1_scratch", ctypes.c_void_p), ("w1_packed", ctypes.c_void_p), ("b1_packed", ctypes.c_void_p),
                 ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("bp", ctypes.c_void_p),
                 ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_stats", ctypes.c_void_p),
+                ("stat_sums", ctypes.c_void_p), ("stat_img_rows", ctypes.c_int64),
                 ("M", ctypes.c_int64), ("C", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("alpha", ctypes.c_float),
                 ("reserved", ctypes.c_int32)]
 
@@ -87,6 +89,7 @@ PROTOTYPES = {
     "vd_gn_table_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P]),
     "vd_gn_affine_from_stats_f16": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "vd_gn_apply_table_f16": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "vd_gn_apply_sums_f16": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _P, _P]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_layernorm_f16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "vd_row_stats_f16": (_I, [_P, _P, _L, _I, _L, _F, _P]),

@@ -148,10 +148,11 @@ class ChanStats(object):
     """Per-channel partial statistics of a tensor, emitted by its producer (VdGemmDesc.out_stats) or by chan_stats():
     buf fp32 [B * T, C, 2] = (mean, M2) over T blocks of HW / T rows per sample.  Travels as the attribute `_vd_stats` of the
     tensor it describes; views / copies do not carry it (the consumer then measures the tensor itself)."""
-    __slots__ = ("buf", "T", "C", "HW")
+    __slots__ = ("buf", "T", "C", "HW", "sums")
 
-    def __init__(self, buf, T, C, HW):
+    def __init__(self, buf, T, C, HW, sums=None):
         self.buf, self.T, self.C, self.HW = buf, int(T), int(C), int(HW)
+        self.sums = sums   # int64 [B * C, 2]: per-(sample, channel) fixed-point sums of the same values (VdGemmDesc.stat_sums), or None
 
 
 def stats_of(t):
@@ -172,7 +173,8 @@ def repeat_batch(t, repeat):
     out = t.repeat(repeat, *([1] * (t.dim() - 1)))
     st = stats_of(t)
     if st is not None:
-        out._vd_stats = ChanStats(st.buf.repeat(repeat, 1, 1), st.T, st.C, st.HW)
+        out._vd_stats = ChanStats(st.buf.repeat(repeat, 1, 1), st.T, st.C, st.HW,
+                                  st.sums.repeat(repeat, 1) if st.sums is not None else None)
     return out
 
 
@@ -418,7 +420,10 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             hw = int(stat_img_rows) if stat_img_rows else (int(d.Hout) * int(d.Wout) if conv is not None else int(M))
             sbuf = torch.empty((int(M) // rows.value, n_out, 2), dtype=torch.float32, device=a0.device)
             d.out_stats = sbuf.data_ptr()
-            stats = ChanStats(sbuf, hw // rows.value, n_out, hw)
+            stats = ChanStats(sbuf, hw // rows.value, n_out, hw, gn_sums_take(int(M) // hw, n_out, hw, a0.device))
+            if stats.sums is not None:
+                d.stat_img_rows = hw
+                d.stat_sums = stats.sums.data_ptr()
     rs_on = False
     if row_sums is not None and LN_SUMS and max(batch, 1) == 1 and row_sums.numel() == 2 * int(M):
         if lib().vd_gemm_row_sums_ok(ctypes.byref(d)):
@@ -479,6 +484,23 @@ class RowSumArena(object):
     def end(self):
         self.need, self.buf = self.used, None
         _tls.arena = None
+
+
+# GroupNorm statistics as ONE pair per (sample, channel) (round 5, VdGemmDesc.stat_sums): producers of tensors large enough for the
+# table + apply pair add their partials into int64 fixed-point sums from the same zeroed arena, and the apply launch folds them itself
+# (vd_gn_apply_sums_f16) -- no vd_gn_table_f32 launch.  VD_GN_SUMS=0: the round-4 pair.
+GN_SUMS = os.environ.get("VD_GN_SUMS", "1") != "0"
+
+
+def gn_sums_take(B, C, HW, device):
+    """Zeroed int64 [B * C, 2] for VdGemmDesc.stat_sums when a GroupNorm over this tensor (alone, or as one half of a skip concat)
+    would take the table + apply pair, else None."""
+    if not GN_SUMS or 2 * B * HW * C <= GN_FUSED_MAX or GN_FORM == "fused":
+        return None
+    arena = getattr(_tls, "arena", None)
+    if arena is not None:
+        return arena.take(B * C, device)
+    return torch.zeros((B * C, 2), dtype=torch.int64, device=device)
 
 
 def rowsum_take(rows, device):
@@ -666,7 +688,9 @@ def ff_chain(x, w1_packed, b1_packed, w2, b2, ln_eps, *, a=None, wo=None, bo=Non
         if want_stats and M % 128 == 0 and hw % 128 == 0:
             sbuf = torch.empty((M // 128, C, 2), dtype=torch.float32, device=x.device)
             d.out_stats = sbuf.data_ptr()
-            stats = ChanStats(sbuf, hw // 128, C, hw)
+            stats = ChanStats(sbuf, hw // 128, C, hw, gn_sums_take(M // hw, C, hw, x.device))
+            if stats.sums is not None:
+                d.stat_sums, d.stat_img_rows = stats.sums.data_ptr(), hw
     nproj = (1 if a is not None else 0) + (1 if wp is not None else 0)
     flops = 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C + nproj * 2.0 * M * C * C
     nm = "ff_chain_kernel<%d,%d>" % (int(a is not None), int(wp is not None))
@@ -723,6 +747,10 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
                 return groupnorm_from_stats(x, gamma, beta, st0, x1=x1, st1=st1, groups=groups, eps=eps, silu=silu, out=out)
             # default: a tiny launch folds the partials into the per-(sample, channel) affine map, the apply launch streams
             # whole rows (measured: the slab-shaped single launch reads 80-byte pieces and ran no faster than the old pair)
+            # round 5: where every source carries its producer's per-(sample, channel) sums the apply launch folds them itself
+            if GN_SUMS and groups <= 32 and st0.sums is not None and (x1 is None or st1.sums is not None):
+                return gn_apply_sums(x, st0.sums, gamma, beta, x1=x1, sums1=st1.sums if x1 is not None else None, groups=groups,
+                                     eps=eps, silu=silu, out=out)
             table = gn_table(st0, gamma, beta, st1=st1, B=B, groups=groups, eps=eps)
             return gn_apply_table(x, table, x1=x1, silu=silu, out=out)
     if out is None:
@@ -801,6 +829,23 @@ def gn_table(st0, gamma, beta, *, st1=None, B, groups=32, eps=1e-5):
                                      st1.T if st1 is not None else 0, st1.C if st1 is not None else 0, B, st0.HW, _ptr(gamma), _ptr(beta),
                                      groups, float(eps), _ptr(table), _stream()))
     return table
+
+
+def gn_apply_sums(x, sums0, gamma, beta, *, x1=None, sums1=None, groups=32, eps=1e-5, silu=True, out=None):
+    """y = act(GroupNorm(cat(x, x1))) from the producers' per-(sample, channel) fixed-point sums (int64 [B * C, 2] each)."""
+    _req(x, "x"); _req(x1, "x1"); _req(gamma, "gamma"); _req(beta, "beta"); _req(sums0, "sums0", torch.int64); _req(sums1, "sums1", torch.int64)
+    B = x.shape[0]
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x.numel() // (B * c0)
+    if sums0.numel() != 2 * B * c0 or (x1 is not None and (sums1 is None or sums1.numel() != 2 * B * c1)):
+        raise VdHipError("gn_apply_sums: the sums do not describe the input tensors")
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x.device)
+    with _Timed("gn_apply_sums_kernel", 0.0, 2.0 * B * HW * (c0 + c1) * 2):
+        _check(lib().vd_gn_apply_sums_f16(_ptr(x), c0, _ptr(sums0), _ptr(x1), c1, _ptr(sums1), B, HW, _ptr(gamma), _ptr(beta), int(groups),
+                                          float(eps), 1 if silu else 0, _ptr(out), _stream()))
+    return out
 
 
 def gn_apply_table(x, table, *, x1=None, silu=True, out=None):
