@@ -203,7 +203,28 @@ __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a
     const int C = a.c0 + a.c1, C8 = C / 8;
     const int tc = tid % a.TC, rl = tid / a.TC;
     const int cg = SUMS ? C / a.groups : 1;
+    const int r0 = blockIdx.x * a.rows_per_chunk;
+    int r1 = r0 + a.rows_per_chunk;
+    if (r1 > a.HW) r1 = a.HW;
+    const size_t rowb = (size_t)b * a.HW;
+    // SUMS: the first batch of rows, gamma and beta of the first octet are requested BEFORE the fold (they do not depend on it), so
+    // the block pays max(fold, row latency), not their sum
+    U4H8 pre[4], gm0, bt0;
     if constexpr (SUMS) {
+        if (rl < a.R) {
+            const int ch = tc * 8;
+            const bool second = ch >= a.c0;
+            const f16* src = second ? a.x1 + (ch - a.c0) : a.x0 + ch;
+            const int ld = second ? a.c1 : a.c0;
+            const int r = r0 + rl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + u * a.R;
+                pre[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : (r < r1 ? r : r0))) * ld);
+            }
+            gm0.u = *reinterpret_cast<const uint4*>(a.gamma + ch);
+            bt0.u = *reinterpret_cast<const uint4*>(a.beta + ch);
+        }
         const int g = tid >> 3, sub = tid & 7;
         double s = 0.0, q = 0.0;
         if (g < a.groups) {
@@ -231,22 +252,22 @@ __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a
         __syncthreads();
     }
     if (rl >= a.R) return;
-    const int r0 = blockIdx.x * a.rows_per_chunk;
-    int r1 = r0 + a.rows_per_chunk;
-    if (r1 > a.HW) r1 = a.HW;
-    const size_t rowb = (size_t)b * a.HW;
     for (int pos = 0; pos < a.npos; ++pos) {
         const int cc = tc + pos * a.TC;
         if (cc >= C8) break;
         const int ch = cc * 8;
         float sc[8], sf[8];
         if constexpr (SUMS) {
-            U4H8 gm, bt;
-            gm.u = *reinterpret_cast<const uint4*>(a.gamma + ch);
-            bt.u = *reinterpret_cast<const uint4*>(a.beta + ch);
+            U4H8 gm = gm0, bt = bt0;
+            if (pos > 0) {
+                gm.u = *reinterpret_cast<const uint4*>(a.gamma + ch);
+                bt.u = *reinterpret_cast<const uint4*>(a.beta + ch);
+            }
+            int g = ch / cg, left = cg - (ch - g * cg);   // channels of group g from ch on
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int g = (ch + q) / cg;
+                if (left == 0) { ++g; left = cg; }
+                --left;
                 sc[q] = gstat[g][1] * (float)gm.e[q];
                 sf[q] = (float)bt.e[q] - gstat[g][0] * sc[q];
             }
@@ -265,7 +286,8 @@ __global__ __launch_bounds__(256) void gn_apply_table_kernel(const GnApplyArgs a
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ru = r + u * a.R;
-                t[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : r)) * ld);
+                if (SUMS && pos == 0 && r == r0 + rl) t[u] = pre[u];
+                else t[u].u = *reinterpret_cast<const uint4*>(src + (rowb + (ru < r1 ? ru : r)) * ld);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -530,7 +552,10 @@ static int gn_apply_launch(const char* who, GnApplyArgs& a, const void* x0, int 
     static const int chunk = chunk_env ? atoi(chunk_env) : 8192;   // 8192: measured best with the light prologue (16384: +0.02 ms, 32768: +0.12)
     static const char* schunk_env = getenv("VD_GN_SUMS_CHUNK");   // the same for the form that folds the producers' sums in its prologue
     static const int schunk = schunk_env ? atoi(schunk_env) : 8192;
+    static const char* srows_env = getenv("VD_GN_SUMS_MINROWS");   // every block of the SUMS form reads its image's sums (16 bytes per channel):
+    static const int srows = srows_env ? atoi(srows_env) : 0;      // at least this many rows per block bound that overhead for wide tensors
     int rpc = (a.table ? chunk : schunk) / C;
+    if (!a.table && rpc < srows) rpc = srows;
     if (rpc < 1) rpc = 1;
     rpc = ((rpc + a.R - 1) / a.R) * a.R;
     if (rpc > HW) rpc = HW;

@@ -488,8 +488,11 @@ class RowSumArena(object):
 
 # GroupNorm statistics as ONE pair per (sample, channel) (round 5, VdGemmDesc.stat_sums): producers of tensors large enough for the
 # table + apply pair add their partials into int64 fixed-point sums from the same zeroed arena, and the apply launch folds them itself
-# (vd_gn_apply_sums_f16) -- no vd_gn_table_f32 launch.  VD_GN_SUMS=0: the round-4 pair.
-GN_SUMS = os.environ.get("VD_GN_SUMS", "1") != "0"
+# (vd_gn_apply_sums_f16) -- no vd_gn_table_f32 launch.  VD_GN_SUMS=1 switches it on; default: the round-4 pair.
+# Measured (five in-session pairs, tools/probes/gn_sums_ab.sh): 27 launches fewer per forward and +0.01 .. +0.04 ms -- the atomics cost the
+# producers 0.045 ms and every apply block re-reads its image's 16 bytes per channel, which eats the table launches it saves.  Opt-in.
+GN_SUMS = os.environ.get("VD_GN_SUMS", "0") != "0"
+GN_SUMS_USE = os.environ.get("VD_GN_SUMS", "0") != "emit"   # development switch: producers accumulate, the consumers keep the table pair
 
 
 def gn_sums_take(B, C, HW, device):
@@ -748,7 +751,7 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
             # default: a tiny launch folds the partials into the per-(sample, channel) affine map, the apply launch streams
             # whole rows (measured: the slab-shaped single launch reads 80-byte pieces and ran no faster than the old pair)
             # round 5: where every source carries its producer's per-(sample, channel) sums the apply launch folds them itself
-            if GN_SUMS and groups <= 32 and st0.sums is not None and (x1 is None or st1.sums is not None):
+            if GN_SUMS and GN_SUMS_USE and groups <= 32 and st0.sums is not None and (x1 is None or st1.sums is not None):
                 return gn_apply_sums(x, st0.sums, gamma, beta, x1=x1, sums1=st1.sums if x1 is not None else None, groups=groups,
                                      eps=eps, silu=silu, out=out)
             table = gn_table(st0, gamma, beta, st1=st1, B=B, groups=groups, eps=eps)
