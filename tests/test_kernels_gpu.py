@@ -768,6 +768,24 @@ def test_attention(ops, dev, B, H, Nq, Nk, D, causal):
     assert rel_l2(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,spike", [(1, 8, 2048, 1024, None), (1, 8, 2100, 1100, 700), (1, 4, 2304, 1089, 1088), (2, 2, 2048, 1088, 3),
+                                              (1, 8, 9216, 9216, 5000), (1, 2, 2048, 1025, 64)])
+def test_attention_staggered_halves(ops, dev, B, H, Nq, Nk, spike):
+    """The 8-wave D = 40 kernel of the 64x64-level self-attention (Nq >= 2048, Nk >= 1024) runs its two half-blocks half an
+    iteration apart over a 4-tile ring (round 5): even / odd tile counts, a last tile of one key, ragged query blocks, the
+    768x768 geometry, and a spiked key (deferred rescale in either half, first / middle / last tile) against fp32."""
+    D = 40
+    C = H * D
+    qkv = rnd((B, max(Nq, Nk), 3 * C), dev, 1.0, 70 + Nk)
+    if spike is not None:
+        qkv[:, spike, C:2 * C] *= 10.0
+    q, k, v = qkv[:, :Nq, :C], qkv[:, :Nk, C:2 * C], qkv[:, :Nk, 2 * C:]
+    ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), H, D ** -0.5, False)
+    out = ops.attention(q, k, v, H)
+    assert bool(torch.isfinite(out).all())
+    assert rel_l2(out, ref) < 3e-3
+
+
 @pytest.mark.parametrize("B,N,D", [(2, 1024, 512), (1, 4096, 512), (1, 1000, 512), (2, 333, 256), (3, 64, 128)])
 def test_attention_one_wide_head(ops, dev, B, N, D):
     """vd_attention_f16 with one head of 128 / 256 / 512 channels (AutoencoderKL mid-block AttnBlock): head dim split over the

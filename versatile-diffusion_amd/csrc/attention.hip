@@ -25,6 +25,12 @@ namespace {
 #ifndef VD_ATTN_MINW
 #define VD_ATTN_MINW 1
 #endif
+#ifndef VD_ATTN_W8_MINW
+#define VD_ATTN_W8_MINW 1
+#endif
+#ifndef VD_ATTN_STAG_MINW
+#define VD_ATTN_STAG_MINW 4   // waves per SIMD the register budget is set for: two 8-wave blocks per CU (<= 128 VGPRs)
+#endif
 constexpr int KV = 64;    // keys per tile
 constexpr float RESCALE_THR = 6.0f;  // log2 units: P values stay <= 64 between rescales
 
@@ -44,8 +50,10 @@ struct AttnArgs {
 
 // NWV waves per block (4, or 8 for long self-attention: the K / V tile's LDS-DMA requests are shared by twice the queries, and
 // request issue is serial time in a wave -- 4 pieces per tile and wave become 2).
-template <int D, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1)) void attn_fwd_kernel(const AttnArgs p) {
+// STAG (8 waves, round 5): the two waves of a SIMD (w and w + 4) run HALF AN ITERATION APART -- while one half of the block is in
+// its softmax (VALU), the other half is in P.V / Q.K^T (matrix pipe); see the loop at the end of the kernel.
+template <int D, int NWV = 4, bool STAG = false>
+__global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? VD_ATTN_W8_MINW : (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1)))) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int QB = 32 * NWV;            // queries per block
     constexpr int KS = (D + 15) / 16;       // k-steps of the QK^T MFMA
     constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T == 32-column panels of the V image
@@ -60,7 +68,9 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
     constexpr bool HAS_ONES = (D % 32) != 0;  // spare rows in the last O^T block: row sums ride on the P.V MFMA (see below)
     constexpr int ONES_COL = D % 32;          // column inside panel DB-1 (a multiple of 8: first half of a 16-byte chunk)
 
-    __shared__ __attribute__((aligned(1024))) char lds_all[NBUF * TILE_BYTES];
+    constexpr int NSLOT = STAG ? 4 : NBUF;    // STAG: ring of 4 tiles (t - 1 .. t + 2 are alive inside iteration t)
+    static_assert(!STAG || (NWV == 8 && 4 * TILE_BYTES <= 64 * 1024), "the staggered loop is built for 8 waves and a 4-tile ring in static LDS");
+    __shared__ __attribute__((aligned(1024))) char lds_all[NSLOT * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,38 +208,36 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_h4_ptr;
 
-    stage(0, 0);
-    // The Q loads are the only VMEM results the compiler tracks: consume them here so its s_waitcnt vmcnt(0) lands before
-    // the loop.  (It cannot see the hand-written waits; left pending, it would drain vmcnt -- and with it the DMA just
-    // issued for the next tile -- in front of the first MFMA of every iteration.)
+    if constexpr (!STAG) {
+        stage(0, 0);
+        // The Q loads are the only VMEM results the compiler tracks: consume them here so its s_waitcnt vmcnt(0) lands before
+        // the loop.  (It cannot see the hand-written waits; left pending, it would drain vmcnt -- and with it the DMA just
+        // issued for the next tile -- in front of the first MFMA of every iteration.)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-    wait_vmcnt<0>();
-    plant_ones(0);
-    __syncthreads();
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+        wait_vmcnt<0>();
+        plant_ones(0);
+        __syncthreads();
+    }
 
-    // One K/V tile.  HAS_NEXT is a compile-time flag: the steady-state iterations fetch tile t+1 unconditionally and the
-    // last tile is peeled.
-    auto tile = [&](const int t, auto has_next) {
-        constexpr bool HAS_NEXT = decltype(has_next)::value;
-        const int cur = (NBUF == 2) ? (t & 1) : 0;
-        const unsigned tbase = lds0 + (unsigned)(cur * TILE_BYTES);
-        const f16* Ks = reinterpret_cast<const f16*>(lds_all + cur * TILE_BYTES);
-        if constexpr (HAS_NEXT && NBUF == 2) stage(t + 1, cur ^ 1);  // lands while this tile is being consumed
-
-        // ---- S^T tiles (keys x queries)
-        f32x16 st[KV / 32];
+    // ---- the three phases of one K/V tile (slot = ring slot of the tile in LDS)
+    f32x16 st[KV / 32];
+    f16x8 pb[KV / 32][2];
+    // S^T tiles (keys x queries): S' = s - m (the running max rides in as the C operand)
+    auto qk = [&](const int slot) __attribute__((always_inline)) {
+        const f16* Ks = reinterpret_cast<const f16*>(lds_all + slot * TILE_BYTES);
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 U4H8 a;
                 a.u = *reinterpret_cast<const uint4*>(Ks + (kt * 32 + l31) * KROW + ks * 16 + hi * 8);
-                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? negm : st[kt], 0, 0, 0);  // S' = s - m
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, qf[ks], ks == 0 ? negm : st[kt], 0, 0, 0);
             }
         }
-
-        // ---- online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
+    };
+    // online softmax for query `qrow`; this lane sees keys key0 + kt*32 + (r&3)+8*(r>>2)+4*hi
+    auto softmax = [&](const int t) __attribute__((always_inline)) {
         const int key0 = t * KV;
         // masking is needed only on the ragged last tile / on tiles that cross the causal diagonal (wave-uniform)
         const bool need_mask = (key0 + KV > p.Nk) || (p.causal && (key0 + KV - 1 > qb * QB + wave * 32 + p.causal - 1));
@@ -269,7 +277,6 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[kt][r] -= delta;
         }
-        f16x8 pb[KV / 32][2];
         if constexpr (HAS_ONES) {
 #pragma unroll
             for (int kt = 0; kt < KV / 32; ++kt)
@@ -291,10 +298,11 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
                 }
             l_run += ps2.x + ps2.y;
         }
-
-        const lds_h4_ptr vbase = (lds_h4_ptr)(size_t)(tbase + v_lane);
-        // ---- O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3):
-        // the A operand is two transpose reads (keys +0..3 and +8..11 of this lane's key half) of row-major V
+    };
+    // O^T += V^T P^T ; k-slot (hi, jj) of step (kt, s) <-> key kt*32 + 16*s + 8*(jj>>2) + 4*hi + (jj&3):
+    // the A operand is two transpose reads (keys +0..3 and +8..11 of this lane's key half) of row-major V
+    auto pv = [&](const int slot) __attribute__((always_inline)) {
+        const lds_h4_ptr vbase = (lds_h4_ptr)(size_t)(lds0 + (unsigned)(slot * TILE_BYTES) + v_lane);
 #pragma unroll
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
@@ -309,6 +317,61 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kt][s], acc[i], 0, 0, 0);
                 }
             }
+    };
+
+    if constexpr (STAG) {
+        // Both halves run the same two phases per tile -- V: softmax(t) -> P;  M: O += P.V(t), S(t + 1) = Q.K(t + 1)^T -- but
+        // waves 4-7 lag HALF an iteration behind waves 0-3, so between two barriers a SIMD sees
+        //     wave w     (early):  softmax(t)          | P.V(t), Q.K(t + 1)
+        //     wave w + 4 (late):   P.V(t - 1), Q.K(t)  | softmax(t)
+        // i.e. one wave's VALU phase beside the other's matrix phase instead of both queueing on the same pipe (lock-step:
+        // pipes 0.47 / 0.51 busy and never together, profiles/r05_pmc_sq.txt).  Alive inside iteration t: tiles t - 1 (late P.V),
+        // t, t + 1 (early Q.K) and t + 2 (in flight) = the 4-slot ring.
+        const bool late = wave >= NWV / 2;
+        stage(0, 0);
+        if (ntiles > 1) stage(1, 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+        wait_vmcnt<0>();
+        plant_ones(0);
+        if (ntiles > 1) plant_ones(1);
+        __syncthreads();
+        // two self-contained loops (same barrier count): one loop with the order chosen inside it made the compiler keep both
+        // halves' live ranges at once (201 VGPRs)
+        auto run = [&](auto is_late) __attribute__((always_inline)) {
+            constexpr bool LATE = decltype(is_late)::value;
+            if constexpr (!LATE) qk(0);
+            for (int t = 0; t < ntiles; ++t) {
+                if (t + 2 < ntiles) stage(t + 2, (t + 2) & 3);   // slot of tile t - 2: its last reader (late P.V) finished before the barrier
+                if constexpr (LATE) {
+                    if (t > 0) pv((t - 1) & 3);
+                    qk(t & 3);
+                    softmax(t);
+                } else {
+                    softmax(t);
+                    pv(t & 3);
+                    if (t + 1 < ntiles) qk((t + 1) & 3);
+                }
+                if (t + 1 < ntiles) {
+                    wait_vmcnt<0>();
+                    if (t + 2 < ntiles) plant_ones((t + 2) & 3);
+                    __syncthreads();
+                }
+            }
+            if constexpr (LATE) pv((ntiles - 1) & 3);
+        };
+        if (late) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+    // One K/V tile.  HAS_NEXT is a compile-time flag: the steady-state iterations fetch tile t+1 unconditionally and the
+    // last tile is peeled.
+    auto tile = [&](const int t, auto has_next) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        const int cur = (NBUF == 2) ? (t & 1) : 0;
+        if constexpr (HAS_NEXT && NBUF == 2) stage(t + 1, cur ^ 1);  // lands while this tile is being consumed
+        qk(cur);
+        softmax(t);
+        pv(cur);
         if constexpr (HAS_NEXT) {
             if constexpr (NBUF == 1) {  // single buffer: refill only after every wave is done with the tile
                 __syncthreads();
@@ -321,6 +384,7 @@ __global__ __launch_bounds__(64 * NWV, (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))
     };
     for (int t = 0; t + 1 < ntiles; ++t) tile(t, std::true_type{});
     tile(ntiles - 1, std::false_type{});
+    }
 
     // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query
     float l_tot;
@@ -571,12 +635,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, OUT* 
     for (int i = tid; i < n; i += 256) pr[i] = (OUT)(__expf(sr[i] * scale - mx) * inv);
 }
 
-template <int D, int NWV = 4>
+template <int D, int NWV = 4, bool STAG = false>
 int launch_attn(AttnArgs a, hipStream_t stream) {
     constexpr int QB = 32 * NWV;
     a.nqb = (a.Nq + QB - 1) / QB;
     a.ctx_map = (a.ctx_map && ((a.BH / a.H * a.nqb) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NWV>), dim3(a.nqb * a.BH), dim3(64 * NWV), 0, stream, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NWV, STAG>), dim3(a.nqb * a.BH), dim3(64 * NWV), 0, stream, a);
     return vd_check_launch("vd_attention_f16");
 }
 
@@ -612,7 +676,14 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
         return launch_attn_wide<512>(a, stream);
     }
     switch (D) {
-        case 40: return w8 ? launch_attn<40, 8>(a, stream) : launch_attn<40>(a, stream);
+        case 40: {
+            // opt-in (VD_ATTN_STAG=1): the half-blocks half an iteration apart.  Correct (test_attention_staggered_halves) and measured
+            // SLOWER: 274-283 us against 265 isolated, forward unchanged; with one block per CU (pure pairing) 313 us -- the two
+            // waves of a SIMD do not overlap one's softmax with the other's MFMAs any better than two lock-stepped blocks do
+            static const char* st_env = getenv("VD_ATTN_STAG");
+            if (w8) return (st_env && st_env[0] == '1') ? launch_attn<40, 8, true>(a, stream) : launch_attn<40, 8>(a, stream);
+            return launch_attn<40>(a, stream);
+        }
         case 64: return launch_attn<64>(a, stream);
         case 80: return launch_attn<80>(a, stream);
         case 160: return launch_attn<160>(a, stream);
