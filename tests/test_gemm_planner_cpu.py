@@ -76,7 +76,8 @@ def test_wide_tile_for_the_64x64_level():
         assert plan(32768, 320, K, ks=ks, halo=0) == (T128x320, 1)     # one block spans all of N: A is read from L2 once
     assert plan(32768, 320, 320) == (T128x64w8, 1)            # short K, many rows: small tiles, 4 waves per SIMD
     assert plan(8192, 640, 640) == (T128x128w8, 1)            # round 5: N = 640 at M >= 8192 takes the 128x128 tile (in-forward A/B)
-    assert plan(4096, 640, 640) == (T128x64w8, 1)
+    assert plan(4096, 640, 640) == (T128x64d, 1)              # ... below that (CFG batch 4) the 4-wave 128x64 tile with three stages
+    assert plan(16384, 320, 320) == (T128x64w8, 1)
     assert plan(2048, 1280, 1280) == (T128x64d, 1)            # 640 blocks of 64x64 -> 320 co-resident 128x64 blocks, three stages
     assert plan(512, 1280, 1280)[0] == T64x64d                # the 8x8 level keeps its (already deep) 64x64 grid
     assert plan(32768, 960, 320) == (T128x320, 1)             # N > 640: the wide tile
@@ -104,6 +105,15 @@ def test_layernorm_fold_uses_fold_instances():
         cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
         assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
         assert cfg.value in fold_ok and ns.value == 1, (M, N, K, cfg.value, ns.value)
+    # q|k|v of the 32x32 level (K = 640) at every workload's row count: 8 waves on the 128x128 tile; the 16x16 level keeps 4 waves
+    for (M, N, K, want) in ((8192, 1920, 640, T128x128w8), (4096, 1920, 640, T128x128w8), (16384, 1920, 640, T128x128w8), (2048, 3840, 1280, T128x128)):
+        d = VdGemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.a0 = d.w = d.out = d.colsum = d.ln_stats = 16
+        d.flags, d.ln_eps = 32, 1e-5
+        cfg, ns = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib().vd_gemm_plan(ctypes.byref(d), ctypes.byref(cfg), ctypes.byref(ns)) == 0
+        assert (cfg.value, ns.value) == (want, 1), (M, N, K, cfg.value)
 
 
 def test_small_m_weight_streaming_splits_k():

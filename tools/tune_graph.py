@@ -3,7 +3,7 @@ pinned through vd_gemm_tune_set, the whole forward is captured into a HIP graph 
 forward (what bench.py's step metric measures), not per-launch events of an eager run.  Greedy over the problems in the order
 given: a winner (>= --min-gain ms) stays installed while the next problem is tried.
 
-    python tools/tune_graph.py [--cfgs 0,1,2,...] [--problems "M,N,K,ks,cls;..."] [--min-gain 0.01]
+    python tools/tune_graph.py [--workload t2i|i2v|dual|triple] [--batch B] [--cfgs 0,1,2,...] [--problems "M,N,K,ks,cls;..."] [--min-gain 0.01]
 
 Prints one line per candidate and the final pins in VD_FWD_TUNE syntax (tools/unet_forward.py)."""
 import argparse
@@ -27,21 +27,23 @@ def main():
     ap.add_argument("--min-gain", type=float, default=0.01)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--top", type=int, default=14)
+    ap.add_argument("--workload", default="t2i", choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="images per forward before CFG doubling (default: the workload's per-GPU share)")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
     problems = [tuple(int(v) for v in p.split(",")) for p in args.problems.split(";") if p]
     dev = torch.device("cuda:0")
     net = bench.build_model(dev)
-    x = torch.randn(8, 4, 64, 64, device=dev, dtype=torch.float16)
-    t = torch.full((8,), 501, device=dev, dtype=torch.long)
-    c = torch.randn(8, 77, 768, device=dev, dtype=torch.float16) * 0.5
-    ci = {"type": "text", "c": c, "kv_cache": {}}
+    wl = bench.WORKLOADS[args.workload]
+    x, t, cs = bench.forward_inputs(wl, args.batch or bench.default_per_gpu(wl), dev)
+    for c in cs:
+        c["kv_cache"] = {}
     h = lib()
     names = [h.vd_gemm_config_name(i).decode() for i in range(h.vd_gemm_num_configs())]
 
     def fwd():
         with torch.no_grad():
-            return net.apply_model({"type": "image", "x": x}, t, ci)
+            return bench.run_forward(net, x, t, cs)
 
     def install(pins):
         h.vd_gemm_tune_clear()

@@ -644,7 +644,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         // large tiles by 7-24 % inside a forward.  Round 5 (re-measured with the repaired epilogues, tools/unet_forward.py with
         // VD_FWD_TUNE pins, same box): at N = 640 and M >= 8192 the 128x128 tile on 8 waves is 6 us per launch faster than the
         // 128x64 one (20 launches per forward: 10.605 -> 10.48-10.50 ms); at N = 320 both tiles measure the same
-        cfg = (d.N > 320 && d.M >= 8192) ? T128x128w8 : T128x64w8;
+        // and at N = 640 with 4096 <= M < 8192 (the 32x32 level at CFG batch 4, BASELINE configs[3]) the 128x64 tile on 4 waves with three
+        // stages wins 0.06 ms per dual-context forward over the 8-wave one (tools/tune_graph.py --workload dual)
+        cfg = (d.N > 320 && d.M >= 8192) ? T128x128w8 : (d.N > 320 ? T128x64d : T128x64w8);
     } else {
         float best = 1e30f;
         const int ns_max = (d.split_k > 0) ? d.split_k : ((can_split && a.kt_total >= 32) ? VD_MAX_SPLIT_K / 2 : 1);
@@ -737,6 +739,11 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
             }
         }
     }
+    // LayerNorm-folded q|k|v of the 32x32 level (K = 640, N = 1920): the 128x128 tile on 8 waves, 0.015 (t2i) .. 0.05 ms (i2v) per
+    // forward over the 4-wave one in all four workloads (tools/tune_graph.py)
+    if (lnfold && !tuned && g_override.load(std::memory_order_relaxed) < 0 && (cfg == T128x128 || cfg == T128x320) && nsplit == 1 && a.kt_total > 5 && a.kt_total <= 10 && d.M >= 4096 &&
+        d.act != VD_ACT_GEGLU)
+        cfg = T128x128w8;
     if (lnfold) {
         // the LayerNorm fold is a compile-time variant of the kernel, instantiated for these tiles only
         switch (cfg) {
