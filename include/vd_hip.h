@@ -243,12 +243,16 @@ int vd_gemm_row320_supported(int64_t M, int N, int K);
 /* The entry of a SpatialTransformer at inner width 320 in one launch (after the statistics): GroupNorm applied as a per-sample
  * affine map -> proj_in -> h (the residual stream, written out), LayerNorm(h) -> fused q | k | v projection:
  *     h = (x * scale[img] + shift[img]) W1^T + b1,     y2 = LayerNorm(h) W2^T + b2
+ * gn_center (ABI 7, may be NULL): fp16 [M / rows_per_image][320] = fp16(group mean) per channel; the map is then applied as
+ * (x - center) * scale + shift with shift = beta - (mean - center) * scale (vd_gn_affine_from_stats_f16 with `center`): x - center is
+ * exact in fp16 near the mean and both operands are O(1), so the fp16 map loses 2^-11 of the NORMALISED value instead of
+ * |mean| / sigma * 2^-11.
  * x, h: fp16 [M][320]; gn_scale / gn_shift: fp16 [M / rows_per_image][320] from vd_groupnorm_affine_f16; w1: fp16 [320][320],
  * b1: fp16 [320]; w2: fp16 [N2][320] with the LayerNorm's gamma folded in, b2: fp16 [N2] = beta W2^T (or NULL); y2: fp16
  * [M][N2], N2 a multiple of 320; rows_per_image a multiple of 128.  Replaces Normalize -> proj_in (lib/model_zoo/
  * attention.py:236-258), norm1 and to_q / to_k / to_v (:214, :170-176) and this library's vd_groupnorm_silu_f16 (apply pass) ->
  * vd_gemm_f16 -> vd_gemm_row320_f16 chain. */
-int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, const void* gn_shift, int rows_per_image, const void* w1,
+int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, const void* gn_shift, const void* gn_center, int rows_per_image, const void* w1,
                              const void* b1, void* h, const void* w2, const void* b2, void* y2, int64_t M, int N2,
                              float ln_eps, hipStream_t stream);
 /* GroupNorm statistics as a per-(sample, channel) affine map: scale = rstd * gamma, shift = beta - mean * scale (fp16 [B][C]),
@@ -337,10 +341,11 @@ int vd_gn_apply_table_f16(const void* x0, int c0, const void* x1, int c1, int B,
 int vd_gn_apply_sums_f16(const void* x0, int c0, const void* sums0, const void* x1, int c1, const void* sums1, int B, int HW,
                          const void* gamma, const void* beta, int groups, float eps, int apply_silu, void* y, hipStream_t stream);
 /* The same map as fp16 [B][C0 + C1] scale / shift vectors: the gn_scale / gn_shift operands of vd_gemm_row320_chain_f16
- * (what vd_groupnorm_affine_f16 computes with a pass over x). */
+ * (what vd_groupnorm_affine_f16 computes with a pass over x).  center (ABI 7, may be NULL): fp16 [B][C0 + C1] = fp16(group mean);
+ * shift is then beta - (mean - center) * scale, for the centred application described at vd_gemm_row320_chain_f16. */
 int vd_gn_affine_from_stats_f16(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
                                 const void* gamma, const void* beta, int groups, float eps, void* scale, void* shift,
-                                hipStream_t stream);
+                                void* center, hipStream_t stream);
 
 /* GroupNorm(groups) [+ SiLU] of the 0-D (text-latent) data flow: FCBlock normalises the flattened [C, sdim] vector of a
  * sample with one affine pair per flat element (reference openaimodel.py:2084-2141 with the [C, sdim, 1] -> C*sdim view

@@ -431,6 +431,32 @@ def test_row320_chain(ops, dev, B, HW, offset):
     assert rel_l2(h, hs.float()) < 3e-3 and rel_l2(y, ys.float()) < 4e-3
 
 
+@pytest.mark.parametrize("offset,sigma", [(0.5, 1.0), (24.0, 0.8), (-60.0, 0.5)])
+def test_row320_chain_centered_map_survives_large_means(ops, dev, offset, sigma):
+    """The chained SpatialTransformer entry applies the GroupNorm as an fp16 map.  With producer statistics the map is centred --
+    (x - fp16(mean)) * scale + shift' -- so its error is 2^-11 of the normalised value; the plain x * scale + shift form loses
+    |mean| / sigma * 2^-11 (shown here at |mean| / sigma = 30 and 120)."""
+    from lib.model_zoo.hip_layers import fold_layernorm
+    B, HW, C = 2, 4096, 320
+    x = (rnd((B, HW, C), dev, sigma, 960).float() + offset + 0.3 * rnd((1, 1, C), dev, sigma, 961).float()).half()
+    gam, bet = 1.0 + 0.2 * rnd((C,), dev, 1.0, 962), 0.1 * rnd((C,), dev, 1.0, 963)
+    w1, b1 = rnd((C, C), dev, C ** -0.5, 964), rnd((C,), dev, 0.2, 965)
+    w2 = rnd((3 * C, C), dev, C ** -0.5, 966)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).to(dev)
+    xn = F.group_norm(x.float().transpose(1, 2), 32, gam.float(), bet.float(), 1e-6).transpose(1, 2)
+    h_ref = xn @ w1.float().t() + b1.float()
+    w2p, b2p, _ = fold_layernorm(w2, None, ln)
+    x._vd_stats = ops.chan_stats(x, 256)   # what a producer attaches
+    sc, sh, ct = ops.groupnorm_affine(x, gam, bet, groups=32, eps=1e-6, centered=True)
+    assert ct is not None
+    h, _ = ops.row320_chain(x, sc, sh, HW, w1, b1, w2p, b2p, 1e-5, center=ct)
+    assert rel_l2(h, h_ref) < 3e-3
+    sc0, sh0 = ops.groupnorm_affine(x, gam, bet, groups=32, eps=1e-6)
+    h0, _ = ops.row320_chain(x, sc0, sh0, HW, w1, b1, w2p, b2p, 1e-5)
+    if abs(offset) / sigma > 20:
+        assert rel_l2(h0, h_ref) > 2 * rel_l2(h, h_ref)   # the plain form is what the centred one repairs
+
+
 @pytest.mark.parametrize("B,H,D,Nq,Nk,offset", [
     (2, 8, 40, 1024, 77, 0.0), (8, 8, 40, 4096, 77, 0.3), (1, 8, 40, 200, 77, -1.5), (2, 8, 80, 256, 257, 0.0),
     (8, 8, 80, 1024, 77, 2.0), (2, 8, 160, 64, 514, 0.0), (3, 8, 160, 100, 77, 0.5), (8, 8, 160, 256, 77, 0.0),

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm320_kernel(const RGArgs p) {
 struct RCArgs {
     const f16* x;       // [M][320]
     const f16* sc;      // [M / rows_per_image][320]  GroupNorm scale  (rstd * gamma)
-    const f16* sh;      // [M / rows_per_image][320]  GroupNorm shift  (beta - mean * scale)
+    const f16* sh;      // [M / rows_per_image][320]  GroupNorm shift  (beta - mean * scale; with `ctr`: beta - (mean - ctr) * scale)
+    const f16* ctr;     // [M / rows_per_image][320]  fp16(mean) per channel or null: x is centred before the scale (no |mean| / sigma loss)
     const f16* w1;      // [320][320]  proj_in
     const f16* b1;      // [320]
     f16* h;             // [M][320]
@@ -370,12 +371,24 @@ __global__ __launch_bounds__(512, 2) void rowchain320_kernel(const RCArgs p) {
         const int img = m0 / p.rows_per_image;
         const f16* scp = p.sc + (size_t)img * RG_C + hi * 8;
         const f16* shp = p.sh + (size_t)img * RG_C + hi * 8;
+        if (p.ctr != nullptr) {   // (uniform) centred form: (x - fp16(mean)) is exact near the mean, scale and shift' are O(1)
+            const f16* ctp = p.ctr + (size_t)img * RG_C + hi * 8;
 #pragma unroll
-        for (int k = 0; k < RG_KT * 4; ++k) {
-            U4H8 a, b;
-            a.u = *reinterpret_cast<const uint4*>(scp + k * 16);
-            b.u = *reinterpret_cast<const uint4*>(shp + k * 16);
-            xf[k] = xf[k] * a.h + b.h;
+            for (int k = 0; k < RG_KT * 4; ++k) {
+                U4H8 a, b, c;
+                a.u = *reinterpret_cast<const uint4*>(scp + k * 16);
+                b.u = *reinterpret_cast<const uint4*>(shp + k * 16);
+                c.u = *reinterpret_cast<const uint4*>(ctp + k * 16);
+                xf[k] = (xf[k] - c.h) * a.h + b.h;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RG_KT * 4; ++k) {
+                U4H8 a, b;
+                a.u = *reinterpret_cast<const uint4*>(scp + k * 16);
+                b.u = *reinterpret_cast<const uint4*>(shp + k * 16);
+                xf[k] = xf[k] * a.h + b.h;
+            }
         }
     }
 
@@ -537,14 +550,14 @@ extern "C" int vd_gemm_row320_f16(const void* x, const void* w, const void* bias
     return layernorm ? launch_rowgemm<true, false>(a, stream) : launch_rowgemm<false, false>(a, stream);
 }
 
-extern "C" int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, const void* gn_shift, int rows_per_image,
+extern "C" int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, const void* gn_shift, const void* gn_center, int rows_per_image,
                                         const void* w1, const void* b1, void* h, const void* w2, const void* b2, void* y2,
                                         int64_t M, int N2, float ln_eps, hipStream_t stream) {
     VD_REQUIRE(x && gn_scale && gn_shift && w1 && b1 && h && w2 && y2, "vd_gemm_row320_chain_f16: null pointer");
     VD_REQUIRE(M > 0 && N2 > 0 && N2 % RG_C == 0 && N2 <= 3072 && M < (1ll << 31) / N2, "vd_gemm_row320_chain_f16: M=%ld N2=%d not supported", (long)M, N2);
     VD_REQUIRE(rows_per_image > 0 && rows_per_image % RG_BM == 0 && M % rows_per_image == 0,
                "vd_gemm_row320_chain_f16: rows per image (%d) must be a multiple of %d and divide M", rows_per_image, RG_BM);
-    VD_REQUIRE((((size_t)x | (size_t)gn_scale | (size_t)gn_shift | (size_t)w1 | (size_t)b1 | (size_t)h | (size_t)w2 | (size_t)b2 | (size_t)y2) & 15) == 0,
+    VD_REQUIRE((((size_t)x | (size_t)gn_scale | (size_t)gn_shift | (size_t)gn_center | (size_t)w1 | (size_t)b1 | (size_t)h | (size_t)w2 | (size_t)b2 | (size_t)y2) & 15) == 0,
                "vd_gemm_row320_chain_f16: operands must be 16-byte aligned");
     constexpr int LDS = RG_LDS + RG_MULTI_EXTRA;
     static std::atomic<unsigned long long> done{0};
@@ -560,7 +573,7 @@ extern "C" int vd_gemm_row320_chain_f16(const void* x, const void* gn_scale, con
         done.fetch_or(bit, std::memory_order_release);
     }
     RCArgs a;
-    a.x = (const f16*)x; a.sc = (const f16*)gn_scale; a.sh = (const f16*)gn_shift; a.w1 = (const f16*)w1; a.b1 = (const f16*)b1;
+    a.x = (const f16*)x; a.sc = (const f16*)gn_scale; a.sh = (const f16*)gn_shift; a.ctr = (const f16*)gn_center; a.w1 = (const f16*)w1; a.b1 = (const f16*)b1;
     a.h = (f16*)h; a.w2 = (const f16*)w2; a.b2 = (const f16*)b2; a.y2 = (f16*)y2;
     a.M = (int)M; a.N2 = N2; a.rows_per_image = rows_per_image; a.eps = ln_eps;
     hipLaunchKernelGGL(rowchain320_kernel, dim3((unsigned)((M + RG_BM - 1) / RG_BM)), dim3(512), LDS, stream, a);

@@ -91,6 +91,7 @@ struct GnTableArgs {
     float eps;
     float* table;                    // [B][2][c0 + c1] (or NULL)
     f16* scale16; f16* shift16;      // optional fp16 [B][c0 + c1] copies (operands of vd_gemm_row320_chain_f16)
+    f16* center16;                   // optional, with scale16: fp16(mean) per channel; shift16 is then relative to it (see below)
 };
 
 // grid (groups, B), ONE wave per (sample, group): the cg x T partials of the group are folded in a single pass around a pivot
@@ -175,8 +176,17 @@ __global__ __launch_bounds__(64) void gn_table_kernel(const GnTableArgs a) {
                 a.table[((size_t)b * 2 + 1) * C + ch] = sh;
             }
             if (a.scale16) {
+                // fp16 operands: x * scale + shift loses |mean| / sigma * 2^-11 to the rounding of scale and shift (both O(|mean| / sigma)).
+                // Centred form: (x - c) * scale + shift' with c = fp16(mean) -- x - c is exact in fp16 near the mean, and
+                // shift' = beta - (mean - c) * scale is O(1), so the error is 2^-11 of the NORMALISED value whatever the offset
                 a.scale16[(size_t)b * C + ch] = (f16)sc;
-                a.shift16[(size_t)b * C + ch] = (f16)sh;
+                if (a.center16) {
+                    const f16 c16 = (f16)mean;
+                    a.center16[(size_t)b * C + ch] = c16;
+                    a.shift16[(size_t)b * C + ch] = (f16)(bet[k] - (mean - (float)c16) * sc);
+                } else {
+                    a.shift16[(size_t)b * C + ch] = (f16)sh;
+                }
             }
         }
     }
@@ -479,23 +489,23 @@ extern "C" int vd_chan_stats_f16(const void* x, long M, int C, int ldx, int rows
 }
 
 static int gn_table_launch(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW, const void* gamma,
-                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, hipStream_t stream);
+                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, void* center16, hipStream_t stream);
 
 extern "C" int vd_gn_table_f32(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
                                const void* gamma, const void* beta, int groups, float eps, float* table, hipStream_t stream) {
     VD_REQUIRE(table, "vd_gn_table_f32: null pointer");
-    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, table, nullptr, nullptr, stream);
+    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, table, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int vd_gn_affine_from_stats_f16(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW,
                                            const void* gamma, const void* beta, int groups, float eps, void* scale, void* shift,
-                                           hipStream_t stream) {
+                                           void* center, hipStream_t stream) {
     VD_REQUIRE(scale && shift, "vd_gn_affine_from_stats_f16: null pointer");
-    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, nullptr, scale, shift, stream);
+    return gn_table_launch(stats0, T0, c0, stats1, T1, c1, B, HW, gamma, beta, groups, eps, nullptr, scale, shift, center, stream);
 }
 
 static int gn_table_launch(const float* stats0, int T0, int c0, const float* stats1, int T1, int c1, int B, int HW, const void* gamma,
-                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, hipStream_t stream) {
+                           const void* beta, int groups, float eps, float* table, void* scale16, void* shift16, void* center16, hipStream_t stream) {
     VD_REQUIRE(stats0 && gamma && beta, "vd_gn_table_f32: null pointer");
     if (!stats1) { T1 = 0; c1 = 0; }
     VD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && groups > 0 && c0 > 0 && c1 >= 0, "vd_gn_table_f32: bad sizes");
@@ -506,7 +516,7 @@ static int gn_table_launch(const float* stats0, int T0, int c0, const float* sta
     a.st1 = reinterpret_cast<const float2*>(stats1); a.T1 = T1; a.c1 = c1;
     a.gamma = reinterpret_cast<const f16*>(gamma); a.beta = reinterpret_cast<const f16*>(beta);
     a.HW = HW; a.groups = groups; a.eps = eps; a.table = table;
-    a.scale16 = reinterpret_cast<f16*>(scale16); a.shift16 = reinterpret_cast<f16*>(shift16);
+    a.scale16 = reinterpret_cast<f16*>(scale16); a.shift16 = reinterpret_cast<f16*>(shift16); a.center16 = reinterpret_cast<f16*>(center16);
     hipLaunchKernelGGL(gn_table_kernel, dim3(groups, B), dim3(64), 0, stream, a);
     return vd_check_launch("vd_gn_table_f32");
 }

@@ -233,10 +233,11 @@ class SpatialTransformer(nn.Module):
         if hip_layers.LN_FOLD and x.is_contiguous() and ops.st_chain_supported(B, H * W, C, inner):
             # GroupNorm (as a per-sample affine map) -> proj_in -> h and LayerNorm(h) -> q | k | v in one launch
             g, b = self.norm._w()
-            sc, sh = ops.groupnorm_affine(x, g, b, groups=self.norm.num_groups, eps=self.norm.eps)
+            # (centred fp16 map: (x - fp16(mean)) * scale + shift', no |mean| / sigma amplification of the fp16 rounding)
+            sc, sh, ct = ops.groupnorm_affine(x, g, b, groups=self.norm.num_groups, eps=self.norm.eps, centered=True)
             w1, b1 = self.proj_in._w()
             w2, b2, _ = blk.attn1._w_qkv_ln(blk.norm1)
-            h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps)
+            h, qkv = ops.row320_chain(x.view(B, H * W, C), sc, sh, H * W, w1, b1, w2, b2, blk.norm1.eps, center=ct)
             pres = x if res is None else res
             post = None
             if pres.is_contiguous() and self.proj_out.out_channels == inner and self.proj_out.bias is not None:

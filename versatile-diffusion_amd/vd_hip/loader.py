@@ -78,7 +78,7 @@ PROTOTYPES = {
     "vd_ff_chain_supported": (_I, [_I]),
     "vd_gemm_row320_f16": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "vd_gemm_row320_supported": (_I, [_L, _I, _I]),
-    "vd_gemm_row320_chain_f16": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "vd_gemm_row320_chain_f16": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "vd_groupnorm_affine_f16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "vd_gemm_tune_set": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vd_gemm_tune_clear": (_I, []),
@@ -87,7 +87,7 @@ PROTOTYPES = {
     "vd_groupnorm_from_stats_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "vd_chan_stats_f16": (_I, [_P, ctypes.c_long, _I, _I, _I, _P, _P]),
     "vd_gn_table_f32": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P]),
-    "vd_gn_affine_from_stats_f16": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
+    "vd_gn_affine_from_stats_f16": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P]),
     "vd_gn_apply_table_f16": (_I, [_P, _I, _P, _I, _I, _I, _P, _I, _P, _P]),
     "vd_gn_apply_sums_f16": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _I, _F, _I, _P, _P]),
     "vd_groupnorm0d_silu_f16": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),

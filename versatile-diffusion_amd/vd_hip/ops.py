@@ -586,8 +586,13 @@ def st_chain_supported(B, HW, C, inner):
     return B * HW // 128 >= cus // 2
 
 
-def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5):
-    """GroupNorm of channels-last x [B, ..., C] as a per-(sample, channel) affine map -> (scale, shift) fp16 [B, C]."""
+ST_CENTER = os.environ.get("VD_ST_CENTER", "1") != "0"   # development switch: 0 = the plain fp16 map x * scale + shift (round 4)
+
+
+def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5, centered=False):
+    """GroupNorm of channels-last x [B, ..., C] as a per-(sample, channel) affine map -> (scale, shift) fp16 [B, C].
+    centered=True -> (scale, shift, center): the map is (x - center) * scale + shift with center = fp16(group mean), which keeps
+    the fp16 operands O(1) whatever |mean| / sigma is (center is None where the statistics have to be measured from x: plain form)."""
     _req(x, "x"); _req(gamma, "gamma"); _req(beta, "beta")
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
@@ -595,21 +600,23 @@ def groupnorm_affine(x, gamma, beta, *, groups=32, eps=1e-5):
     sh = torch.empty((B, C), dtype=torch.float16, device=x.device)
     st = stats_of(x) if GN_STATS else None
     if st is not None and C % groups == 0:   # statistics from the producer: no pass over x
+        ct = torch.empty((B, C), dtype=torch.float16, device=x.device) if (centered and ST_CENTER) else None
         with _Timed("gn_table_kernel", 0.0, 0.0):
             _check(lib().vd_gn_affine_from_stats_f16(_ptr(st.buf), st.T, st.C, None, 0, 0, B, HW, _ptr(gamma), _ptr(beta), groups,
-                                                     float(eps), _ptr(sc), _ptr(sh), _stream()))
-        return sc, sh
+                                                     float(eps), _ptr(sc), _ptr(sh), _ptr(ct), _stream()))
+        return (sc, sh, ct) if centered else (sc, sh)
     ws = workspace(lib().vd_groupnorm_workspace_bytes(B, HW, C, groups), x.device, "gn")
     with _Timed("groupnorm statistics -> affine", 0.0, 2.0 * B * HW * C):
         _check(lib().vd_groupnorm_affine_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(sc), _ptr(sh), _ptr(ws), B, HW, C, groups,
                                              float(eps), _stream()))
-    return sc, sh
+    return (sc, sh, None) if centered else (sc, sh)
 
 
-def row320_chain(x, sc, sh, rows_per_image, w1, b1, w2, b2, ln_eps):
+def row320_chain(x, sc, sh, rows_per_image, w1, b1, w2, b2, ln_eps, center=None):
     """h = (x * sc[img] + sh[img]) @ w1^T + b1;  y2 = LayerNorm(h) @ w2^T + b2 (w2 / b2 LayerNorm-folded) in one launch
-    (vd_gemm_row320_chain_f16).  x [..., 320] contiguous -> (h [..., 320], y2 [..., N2])."""
-    for t, n in ((x, "x"), (sc, "sc"), (sh, "sh"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+    (vd_gemm_row320_chain_f16).  x [..., 320] contiguous -> (h [..., 320], y2 [..., N2]).  center (fp16 [images, 320], from
+    groupnorm_affine(centered=True)): the map is applied as (x - center) * sc + sh."""
+    for t, n in ((x, "x"), (sc, "sc"), (sh, "sh"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (center, "center")):
         _req(t, n)
     M = x.numel() // 320
     N2 = w2.shape[0]
@@ -617,7 +624,7 @@ def row320_chain(x, sc, sh, rows_per_image, w1, b1, w2, b2, ln_eps):
     y2 = torch.empty(x.shape[:-1] + (N2,), dtype=torch.float16, device=x.device)
     name = "rowchain320_kernel" + ((" M=%d N2=%d" % (M, N2)) if PROFILE_SHAPES else "")
     with _Timed(name, 2.0 * M * 320 * (320 + N2), 2.0 * (2 * M * 320 + M * N2 + 320 * (320 + N2))):
-        _check(lib().vd_gemm_row320_chain_f16(_ptr(x), _ptr(sc), _ptr(sh), int(rows_per_image), _ptr(w1), _ptr(b1), _ptr(h),
+        _check(lib().vd_gemm_row320_chain_f16(_ptr(x), _ptr(sc), _ptr(sh), _ptr(center), int(rows_per_image), _ptr(w1), _ptr(b1), _ptr(h),
                                               _ptr(w2), _ptr(b2), _ptr(y2), M, N2, float(ln_eps), _stream()))
     return h, y2
 
