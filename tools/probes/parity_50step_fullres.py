@@ -5,6 +5,8 @@ path (graph-replayed sampler loop through the C ABI) against the fp32 CPU oracle
 trajectory every 10 steps.  The oracle's 50 forwards take ~4 minutes on 16 host threads.
 
     python tools/probes/parity_50step_fullres.py [out.txt]            on the GPU box
+    python tools/probes/parity_50step_fullres.py --dual --steps 20 [out.txt]   BASELINE configs[3]'s geometry: text (L = 77) +
+                                                   image (L = 257) context mixing 0.5 / 0.5 through sample_multicontext
     python tools/probes/parity_50step_fullres.py --dry                oracle side only, 2 steps at 16x16 (CPU container)
 """
 import os
@@ -22,8 +24,11 @@ from vdtest_util import full_vd_cfg, rel_l2, synth_into
 from oracle import vd_oracle as O
 
 DRY = "--dry" in sys.argv
-OUT = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
-STEPS, SIDE, EVERY = (2, 16, 1) if DRY else (50, 64, 10)
+DUAL = "--dual" in sys.argv
+_args = [a for a in sys.argv[1:]]
+_steps = int(_args[_args.index("--steps") + 1]) if "--steps" in _args else 50
+OUT = next((a for i, a in enumerate(_args) if not a.startswith("--") and (i == 0 or _args[i - 1] != "--steps")), None)
+STEPS, SIDE, EVERY = (2, 16, 1) if DRY else (_steps, 64, 10 if _steps >= 50 else 5)
 LATENT_TOL = 1e-2   # north star: <= 1e-2 rel-L2 vs reference latents
 
 
@@ -44,7 +49,9 @@ def main():
     xT = torch.randn((1, 4, SIDE, SIDE), generator=g)
     c = torch.randn((1, 77, 768), generator=g) * 0.5
     u = torch.randn((1, 77, 768), generator=g) * 0.5
-    say("50-step full-resolution parity: steps %d, latent %dx%d, B = 1 (CFG batch 2), guidance 7.5, eta 0" % (STEPS, SIDE, SIDE))
+    ci = torch.randn((1, 257, 768), generator=g) * 0.5
+    say("full-resolution loop parity (%s): steps %d, latent %dx%d, B = 1 (CFG batch 2), guidance 7.5, eta 0" % (
+        "dual context: text 77 + image 257, ratios 0.5 / 0.5" if DUAL else "text context", STEPS, SIDE, SIDE))
 
     z = inter = None
     if not DRY:
@@ -55,9 +62,17 @@ def main():
         net.to(dev)
         sampler = DDIMSampler(net)
         t0 = time.time()
-        z, inter = sampler.sample(steps=STEPS, shape=[1, 4, SIDE, SIDE], x_info={"type": "image", "xt": xT.half().to(dev)},
-                                  c_info={"type": "text", "conditioning": c.half().to(dev), "unconditional_conditioning": u.half().to(dev),
-                                          "unconditional_guidance_scale": 7.5}, eta=0., verbose=False, log_every_t=EVERY)
+        h = lambda t: t.half().to(dev)
+        ct = {"type": "text", "conditioning": h(c), "unconditional_conditioning": h(u), "unconditional_guidance_scale": 7.5}
+        if DUAL:
+            ct["ratio"] = 0.5
+            cim = {"type": "image", "conditioning": h(ci), "unconditional_conditioning": h(torch.zeros_like(ci)),
+                   "unconditional_guidance_scale": 7.5, "ratio": 0.5}
+            z, inter = sampler.sample_multicontext(steps=STEPS, shape=[1, 4, SIDE, SIDE], x_info={"type": "image", "xt": h(xT)},
+                                                   c_info_list=[ct, cim], eta=0., verbose=False, log_every_t=EVERY)
+        else:
+            z, inter = sampler.sample(steps=STEPS, shape=[1, 4, SIDE, SIDE], x_info={"type": "image", "xt": h(xT)},
+                                      c_info=ct, eta=0., verbose=False, log_every_t=EVERY)
         torch.cuda.synchronize()
         say("HIP path: library %s, graph loop %s, %.2f s (first call: capture included), %d logged latents" % (
             lib_digest(), sampler.use_graph, time.time() - t0, len(inter["pred_xt"])))
@@ -68,6 +83,9 @@ def main():
     sched = O.ddim_schedule(sd["alphas_cumprod"], STEPS, 0.0)
     ts = sched["timesteps"]
     ctx = [{"type": "text", "conditioning": c, "unconditional_conditioning": u}]
+    if DUAL:
+        ctx = [{"type": "text", "conditioning": c, "unconditional_conditioning": u, "ratio": 0.5},
+               {"type": "image", "conditioning": ci, "unconditional_conditioning": torch.zeros_like(ci), "ratio": 0.5}]
     x = xT
     logged = []
     t0 = time.time()
@@ -88,7 +106,7 @@ def main():
         return
     assert len(inter) == len(logged), (len(inter), len(logged))
     err = rel_l2(z, x)
-    say("final latent rel-L2 vs fp32 oracle after %d steps: %.3e (tolerance %.0e) -> %s" % (STEPS, err, LATENT_TOL, "PASS" if err < LATENT_TOL else "FAIL"))
+    say("final latent rel-L2 vs fp32 oracle after %d DDIM timesteps: %.3e (tolerance %.0e) -> %s" % (int(ts.shape[0]), err, LATENT_TOL, "PASS" if err < LATENT_TOL else "FAIL"))
     sys.exit(0 if err < LATENT_TOL else 1)
 
 
