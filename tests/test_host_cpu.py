@@ -364,3 +364,74 @@ def test_graft_entry_build_runs():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=root, capture_output=True, text=True,
                        timeout=3000)
     assert r.returncode == 0 and "build ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_sampler_static_state_is_keyed_by_geometry_flow_and_weight_versions():
+    """DDIMSampler._static_state (the buffers a kept step graph reads): one entry per (weights, latent shape, flow, contexts),
+    at most two kept, most recently used last; an in-place weight update or a moved parameter gets a NEW entry (the kept
+    graph would otherwise replay against weight packs of the old values)."""
+    import torch
+    from lib.model_zoo.ddim import DDIMSampler
+
+    class Net(torch.nn.Module):
+        num_timesteps = 1000
+
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 4)
+
+    net = Net()
+    s = DDIMSampler(net)
+    x = torch.zeros(2, 4, 8, 8, dtype=torch.float16)
+    ctx = lambda L: [{"type": "text", "c": torch.zeros(4, L, 768), "ratio": 1.0}]
+    a = s._static_state(x, {"type": "image"}, ctx(77), True, True)
+    assert a["xs"].shape == x.shape and a["ts"].shape == (4,) and a["c"][0].shape == (4, 77, 768) and a["graph"] is None
+    assert s._static_state(x, {"type": "image"}, ctx(77), True, True) is a
+    b = s._static_state(x, {"type": "image"}, ctx(257), True, True)          # another context length
+    assert b is not a and len(s._static) == 2
+    assert s._static_state(x, {"type": "image"}, ctx(77), True, True) is a    # a is now the most recently used
+    c = s._static_state(x[:1], {"type": "image"}, ctx(77)[:1], False, True)   # third geometry: the oldest (b) goes
+    assert c["ts"].shape == (1,) and len(s._static) == 2
+    assert s._static_state(x, {"type": "image"}, ctx(77), True, True) is a
+    assert s._static_state(x, {"type": "image"}, ctx(257), True, True) is not b
+    with torch.no_grad():
+        net.lin.weight.add_(1.0)                                              # in-place update: version bump
+    assert s._static_state(x, {"type": "image"}, ctx(77), True, True) is not a
+    s.release_graphs()
+    assert len(s._static) == 0
+    s.graph_cache = False
+    assert s._static_state(x, {"type": "image"}, ctx(77), True, True) is None
+
+
+def test_coef_table_rows_are_the_ddim_update_of_the_reference():
+    """DDIMSampler._coef_table feeds cfg_ddim_dev_kernel: {scale, 1/sqrt(a_t), sqrt(a_prev), sqrt(1 - a_prev - sigma^2), sigma,
+    sqrt(1 - a_t)} per DDIM index -- the coefficients of p_sample_ddim (reference ddim.py:150-171), from the bit-exact schedule."""
+    import numpy as np
+    import torch
+    from lib.model_zoo.ddim import DDIMSampler
+    from lib.model_zoo.diffusion_utils import make_beta_schedule
+
+    class Net(object):
+        num_timesteps = 1000
+
+        def host_schedule(self, name):
+            betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+            return np.cumprod(1.0 - np.asarray(betas, dtype=np.float64), axis=0)
+
+    for steps, eta in ((50, 0.0), (20, 0.7)):
+        s = DDIMSampler(Net())
+        s.make_schedule(steps, ddim_eta=eta, verbose=False)
+        n = s.ddim_timesteps.shape[0]
+        tab = s._coef_table(n, 7.5, torch.device("cpu")).numpy()
+        assert tab.shape == (n, 6) and tab.dtype == np.float32
+        a_t, a_prev, sig = s.ddim_alphas.astype(np.float64), s.ddim_alphas_prev.astype(np.float64), s.ddim_sigmas.astype(np.float64)
+        x, e = 0.3, -1.1   # one element through the update, reference order of operations in fp64
+        for i in range(n):
+            pred_x0 = (x - float(s.ddim_sqrt_one_minus_alphas[i]) * e) / np.sqrt(a_t[i])
+            x_prev = np.sqrt(a_prev[i]) * pred_x0 + np.sqrt(max(1.0 - a_prev[i] - sig[i] ** 2, 0.0)) * e
+            sc, r_at, s_ap, dirc, sg, s1m = [float(v) for v in tab[i]]
+            assert sc == 7.5 and sg == np.float32(sig[i])
+            got = s_ap * ((x - s1m * e) * r_at) + dirc * e
+            assert abs(got - x_prev) < 2e-6 * max(1.0, abs(x_prev))
+        if eta == 0.0:
+            assert not sig.any()
