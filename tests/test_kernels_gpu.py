@@ -4,6 +4,7 @@ All calls go through the C ABI (ctypes -> libvd_hip.so).  Tolerances are stated 
 fp16-rounded so the only differences are accumulation order / fp16 output rounding.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -794,22 +795,29 @@ def test_attention(ops, dev, B, H, Nq, Nk, D, causal):
     assert rel_l2(out, ref) < 3e-3
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,spike", [(1, 8, 2048, 1024, None), (1, 8, 2100, 1100, 700), (1, 4, 2304, 1089, 1088), (2, 2, 2048, 1088, 3),
-                                              (1, 8, 9216, 9216, 5000), (1, 2, 2048, 1025, 64)])
-def test_attention_staggered_halves(ops, dev, B, H, Nq, Nk, spike):
-    """The 8-wave D = 40 kernel of the 64x64-level self-attention (Nq >= 2048, Nk >= 1024) runs its two half-blocks half an
-    iteration apart over a 4-tile ring (round 5): even / odd tile counts, a last tile of one key, ragged query blocks, the
-    768x768 geometry, and a spiked key (deferred rescale in either half, first / middle / last tile) against fp32."""
+@pytest.mark.parametrize("B,H,Nq,Nk,spike,gain", [(1, 8, 2048, 1024, None, 1.0), (1, 8, 2100, 1100, 700, 1.0), (1, 4, 2304, 1089, 1088, 1.0),
+                                                   (2, 2, 2048, 1088, 3, 1.0), (1, 8, 9216, 9216, 5000, 1.0), (1, 2, 2048, 1025, 64, 1.0),
+                                                   (1, 2, 2560, 1024, 40, 1.0), (1, 4, 2048, 2048, 1500, 3.0), (3, 3, 2048, 1030, None, 2.5)])
+def test_attention_pipelined_long(ops, dev, B, H, Nq, Nk, spike, gain):
+    """`attn_pipe_kernel` (D = 40, Nq >= 2048, Nk >= 1024: the 64x64 / 96x96-level self-attention; 64 queries per wave, software-
+    pipelined at 32-key steps over a 4-slot ring, running max in Q's spare k-slot as an fp16 value, constant LDS columns -- round 6)
+    against fp32: even / odd tile counts, a last tile of one or six keys, ragged query blocks (one row block of a wave empty), a
+    block count that is not a multiple of 8, the 768x768 geometry, a spiked key in the first / a middle / the last tile (deferred
+    rescale with scores and probabilities in flight) and logits of +-40 (the fp16-rounded max must keep P finite)."""
     D = 40
     C = H * D
     qkv = rnd((B, max(Nq, Nk), 3 * C), dev, 1.0, 70 + Nk)
+    qkv[..., :2 * C] *= gain
     if spike is not None:
-        qkv[:, spike, C:2 * C] *= 10.0
+        qkv[:, spike, C:2 * C] *= 10.0 / gain
     q, k, v = qkv[:, :Nq, :C], qkv[:, :Nk, C:2 * C], qkv[:, :Nk, 2 * C:]
     ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), H, D ** -0.5, False)
     out = ops.attention(q, k, v, H)
     assert bool(torch.isfinite(out).all())
-    assert rel_l2(out, ref) < 3e-3
+    assert rel_l2(out, ref) < (3e-3 if gain == 1.0 else 5e-3)
+    if gain == 1.0 and spike is None:
+        out4 = ops.attention(q[:, :1024], k, v, H)   # Nq < 2048: the serial 4-wave kernel on the same keys
+        assert rel_l2(out[:, :1024], out4) < 2e-3
 
 
 @pytest.mark.parametrize("B,N,D", [(2, 1024, 512), (1, 4096, 512), (1, 1000, 512), (2, 333, 256), (3, 64, 128)])

@@ -15,7 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 # VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
 OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
 SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "conv_wstream.hip", "ff_fused.hip", "ff_chain.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
-HEADERS = [os.path.join(CSRC, "vd_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "conv_halo_kernel.h"), os.path.join(CSRC, "conv_wstream_kernel.h"), os.path.join(CSRC, "conv_wreg_kernel.h"), os.path.join(CSRC, "gemm_wstream_kernel.h"), os.path.join(HERE, "..", "include", "vd_hip.h")]
+# every header under csrc/ (a kernel header that is not hashed would let a stale library pass the stamp check)
+import glob
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "vd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 # keep MFMA results in VGPRs where VALU code consumes them right away (softmax on the S tile): avoids the
 # v_accvgpr_read/write shuffle and lowers the register footprint (2 -> 3 waves/SIMD for head dim 40)

@@ -28,9 +28,6 @@ namespace {
 #ifndef VD_ATTN_W8_MINW
 #define VD_ATTN_W8_MINW 1
 #endif
-#ifndef VD_ATTN_STAG_MINW
-#define VD_ATTN_STAG_MINW 4   // waves per SIMD the register budget is set for: two 8-wave blocks per CU (<= 128 VGPRs)
-#endif
 constexpr int KV = 64;    // keys per tile
 constexpr float RESCALE_THR = 6.0f;  // log2 units: P values stay <= 64 between rescales
 
@@ -50,10 +47,8 @@ struct AttnArgs {
 
 // NWV waves per block (4, or 8 for long self-attention: the K / V tile's LDS-DMA requests are shared by twice the queries, and
 // request issue is serial time in a wave -- 4 pieces per tile and wave become 2).
-// STAG (8 waves, round 5): the two waves of a SIMD (w and w + 4) run HALF AN ITERATION APART -- while one half of the block is in
-// its softmax (VALU), the other half is in P.V / Q.K^T (matrix pipe); see the loop at the end of the kernel.
-template <int D, int NWV = 4, bool STAG = false>
-__global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? VD_ATTN_W8_MINW : (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1)))) void attn_fwd_kernel(const AttnArgs p) {
+template <int D, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 ? VD_ATTN_W8_MINW : (D <= 64 && NWV == 4 ? VD_ATTN_MINW : 1))) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int QB = 32 * NWV;            // queries per block
     constexpr int KS = (D + 15) / 16;       // k-steps of the QK^T MFMA
     constexpr int DB = (D + 31) / 32;       // 32-row blocks of O^T == 32-column panels of the V image
@@ -68,9 +63,7 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
     constexpr bool HAS_ONES = (D % 32) != 0;  // spare rows in the last O^T block: row sums ride on the P.V MFMA (see below)
     constexpr int ONES_COL = D % 32;          // column inside panel DB-1 (a multiple of 8: first half of a 16-byte chunk)
 
-    constexpr int NSLOT = STAG ? 4 : NBUF;    // STAG: ring of 4 tiles (t - 1 .. t + 2 are alive inside iteration t)
-    static_assert(!STAG || (NWV == 8 && 4 * TILE_BYTES <= 64 * 1024), "the staggered loop is built for 8 waves and a 4-tile ring in static LDS");
-    __shared__ __attribute__((aligned(1024))) char lds_all[NSLOT * TILE_BYTES];
+    __shared__ __attribute__((aligned(1024))) char lds_all[NBUF * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,7 +201,7 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_h4_ptr;
 
-    if constexpr (!STAG) {
+    {
         stage(0, 0);
         // The Q loads are the only VMEM results the compiler tracks: consume them here so its s_waitcnt vmcnt(0) lands before
         // the loop.  (It cannot see the hand-written waits; left pending, it would drain vmcnt -- and with it the DMA just
@@ -255,11 +248,13 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
         for (int kt = 0; kt < KV / 32; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[kt][r]), st[kt][r + 1]);  // v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // max of S' = how far this tile exceeds the running max
         // Deferred rescale: accumulators and running max move only when some row grew by more than RESCALE_THR (then every
         // lane updates exactly); otherwise P = exp2(S') <= 2^RESCALE_THR, harmless in fp16/fp32.  The first tile always
         // takes this path (m starts at 0, the first row max may be far below it).
+        // (the vote needs no cross-lane exchange -- `any lane above` is the same before and after it: the LDS round trip of the
+        // exchange is paid only where the shift is applied)
         if (t == 0 || __any(mx > RESCALE_THR)) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // max of S' = how far this tile exceeds the running max; both lanes of a query agree
             float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
             if (mx == -INFINITY) delta = 0.f;  // fully masked row so far: nothing to shift
             if (t != 0) {  // nothing accumulated yet on the first tile
@@ -319,50 +314,6 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
             }
     };
 
-    if constexpr (STAG) {
-        // Both halves run the same two phases per tile -- V: softmax(t) -> P;  M: O += P.V(t), S(t + 1) = Q.K(t + 1)^T -- but
-        // waves 4-7 lag HALF an iteration behind waves 0-3, so between two barriers a SIMD sees
-        //     wave w     (early):  softmax(t)          | P.V(t), Q.K(t + 1)
-        //     wave w + 4 (late):   P.V(t - 1), Q.K(t)  | softmax(t)
-        // i.e. one wave's VALU phase beside the other's matrix phase instead of both queueing on the same pipe (lock-step:
-        // pipes 0.47 / 0.51 busy and never together, profiles/r05_pmc_sq.txt).  Alive inside iteration t: tiles t - 1 (late P.V),
-        // t, t + 1 (early Q.K) and t + 2 (in flight) = the 4-slot ring.
-        const bool late = wave >= NWV / 2;
-        stage(0, 0);
-        if (ntiles > 1) stage(1, 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-        wait_vmcnt<0>();
-        plant_ones(0);
-        if (ntiles > 1) plant_ones(1);
-        __syncthreads();
-        // two self-contained loops (same barrier count): one loop with the order chosen inside it made the compiler keep both
-        // halves' live ranges at once (201 VGPRs)
-        auto run = [&](auto is_late) __attribute__((always_inline)) {
-            constexpr bool LATE = decltype(is_late)::value;
-            if constexpr (!LATE) qk(0);
-            for (int t = 0; t < ntiles; ++t) {
-                if (t + 2 < ntiles) stage(t + 2, (t + 2) & 3);   // slot of tile t - 2: its last reader (late P.V) finished before the barrier
-                if constexpr (LATE) {
-                    if (t > 0) pv((t - 1) & 3);
-                    qk(t & 3);
-                    softmax(t);
-                } else {
-                    softmax(t);
-                    pv(t & 3);
-                    if (t + 1 < ntiles) qk((t + 1) & 3);
-                }
-                if (t + 1 < ntiles) {
-                    wait_vmcnt<0>();
-                    if (t + 2 < ntiles) plant_ones((t + 2) & 3);
-                    __syncthreads();
-                }
-            }
-            if constexpr (LATE) pv((ntiles - 1) & 3);
-        };
-        if (late) run(std::true_type{});
-        else run(std::false_type{});
-    } else {
     // One K/V tile.  HAS_NEXT is a compile-time flag: the steady-state iterations fetch tile t+1 unconditionally and the
     // last tile is peeled.
     auto tile = [&](const int t, auto has_next) {
@@ -384,7 +335,6 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
     };
     for (int t = 0; t + 1 < ntiles; ++t) tile(t, std::true_type{});
     tile(ntiles - 1, std::false_type{});
-    }
 
     // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query
     float l_tot;
@@ -411,6 +361,354 @@ __global__ __launch_bounds__(64 * NWV, (STAG ? VD_ATTN_STAG_MINW : (NWV == 8 ? V
                 }
             }
     }
+}
+
+// ---- long self-attention, head dim 40 (64x64 / 96x96 latents: lib/model_zoo/attention.py:170-193 with N = 4096 / 9216).
+// Round 6.  SQ counters of the serial loop above (profiles/r05_pmc_sq.txt, tools/probes/attn_pmc.sh) show a SIMD that ISSUES
+// instructions 88 % of its cycles while its matrix pipe is 0.52 busy: per 64-key tile and wave 14 MFMAs ride on ~130 other
+// instructions (VALU 77, LDS 24, SALU 26, LDS-DMA 2) at ~5 cycles of issue each, and an ablation of a software-pipelined
+// variant put numbers on each class (MFMAs alone 121 us of 306; LDS reads +67, row max +60, tile boundary +59 of which the two
+// DMA requests +33, exp2 +45).  So this kernel spends fewer instructions per MFMA:
+//   * a wave owns 64 queries (two 32-row blocks): K / V fragments, LDS-DMA requests, barriers and loop control are shared by
+//     twice the MFMAs (22 LDS reads per 28 MFMAs instead of per 14);
+//   * the threshold vote of the deferred rescale is ONE max over both row blocks, with no cross-lane exchange (the exchange
+//     and the exact per-block maxima live in the rare branch);
+//   * K and V sit in LDS slot-major ([16-byte chunk][key]), so a tile is 10 DMA pieces instead of 15 (no padding chunks
+//     travel) and the constant columns -- the 1.0 behind V's column D that makes the P.V MFMA produce the row sums, and a
+//     1.0 behind K's column D -- are written ONCE per ring slot instead of planted per tile;
+//   * the running max m of a query rides in Q's spare k-slot D (as -m in fp16, against that constant 1.0 of K): the MFMA
+//     subtracts it, S' = s - m leaves the matrix core ready for exp2 and no VGPR holds -m as a C operand.  m is kept as the
+//     fp16 value that is actually subtracted, so the algebra stays exact: shifts are differences of representable values.
+// The loop is software-pipelined inside the wave at half-tile (32-key) steps -- step h carries Q.K^T of step h + 1, the
+// exp2 / pack of step h and P.V of step h - 1, pinned into one interleaved stream with sched_group_barrier -- and the fragment
+// registers alternate: V fragments load under the Q.K^T MFMAs and are consumed by P.V, K fragments of the next step load
+// under P.V.  Ring of 4 tile slots (slot = tile & 3), one barrier per tile.
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_pipe_kernel(const AttnArgs p) {
+    static_assert(D == 40, "built for head dim 40: 3 k-steps with a spare slot at D, 2 V panels with a spare column at D");
+    constexpr int NWV = 8, RB = 2;          // waves per block, 32-row query blocks per wave
+    constexpr int QB = 32 * RB * NWV;       // 512 queries per block
+    constexpr int KS = 3, DB = 2;
+    constexpr int NKC = D / 8;              // 5 data chunks per K row
+    constexpr int K_BYTES = (NKC + 1) * 1024;            // [chunk 0..4 | constant chunk 5][64 keys][16 B]
+    constexpr int V0_BYTES = 4096;                       // panel 0: [64 keys][32 halfs]
+    constexpr int V1_STRIDE = 1024 + 64;                 // panel 1 chunks staggered by 64 B: the three chunk groups of a transpose read hit different banks
+    constexpr int V1_BYTES = 3 * V1_STRIDE + 64;         // chunk 0 = d 32..39 (DMA), chunk 1 = {1, 0 x 7} (constant), chunk 2 = zeros (constant)
+    constexpr int SLOT_BYTES = ((K_BYTES + V0_BYTES + V1_BYTES + 1023) / 1024) * 1024;   // 14 KiB
+    constexpr int NPIECE = NKC + 4 + 1;     // DMA pieces per tile: 5 K chunks, 4 x 16 keys of panel 0, chunk 0 of panel 1
+    constexpr int NSLOT = 4;                // ring: tile t - 1 still feeds P.V while t + 1 feeds Q.K^T and t + 2 is in flight
+    static_assert(NSLOT * SLOT_BYTES <= 64 * 1024, "static LDS");
+    __shared__ __attribute__((aligned(1024))) char lds_all[NSLOT * SLOT_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    int qb, bh;
+    {
+        const int bid = blockIdx.x;
+        if ((p.BH & 7) == 0) {   // an XCD owns BH / 8 consecutive (batch, head) pairs: K / V of a pair stay in one L2
+            const int xcd = bid & 7, idx = bid >> 3;
+            bh = xcd * (p.BH >> 3) + idx / p.nqb;
+            qb = idx % p.nqb;
+        } else {
+            bh = bid / p.nqb;
+            qb = bid % p.nqb;
+        }
+    }
+    const int b = bh / p.H, h = bh % p.H;
+    const f16* qp = p.q + (size_t)b * p.sq + h * D;
+    const f16* kp = p.k + (size_t)b * p.sk + h * D;
+    const f16* vp = p.v + (size_t)b * p.sv + h * D;
+    f16* op = p.o + (size_t)b * p.so + h * D;
+
+    // ---- staging plan: piece j of a tile is 1 KiB of LDS = lane * 16 bytes (buffer_load ... lds); rows past Nk fall outside
+    // the descriptor and read as zeros.  Wave w requests piece w, waves 0 / 1 also pieces 8 / 9.
+    const i32x4 rs_k = make_rsrc_words(kp, (unsigned)(((size_t)(p.Nk - 1) * p.ldk + D) * 2));
+    const i32x4 rs_v = make_rsrc_words(vp, (unsigned)(((size_t)(p.Nk - 1) * p.ldv + D) * 2));
+    auto piece_voff = [&](const int j) -> unsigned {
+        if (j < NKC) return (unsigned)((lane * p.ldk + j * 8) * 2);                                              // K chunk j: key = lane
+        if (j < NKC + 4) return (unsigned)((((j - NKC) * 16 + (lane >> 2)) * p.ldv + (lane & 3) * 8) * 2);       // panel 0, keys 16 (j - 5) ..
+        return (unsigned)((lane * p.ldv + 32) * 2);                                                              // panel 1 chunk 0: key = lane
+    };
+    auto piece_dst = [&](const int j) -> unsigned {
+        return j < NKC ? (unsigned)(j * 1024) : (j < NKC + 4 ? (unsigned)(K_BYTES + (j - NKC) * 1024) : (unsigned)(K_BYTES + V0_BYTES));
+    };
+    const bool a_is_k = wave < NKC;
+    const i32x4 rs_a = a_is_k ? rs_k : rs_v;
+    unsigned voff_a = piece_voff(wave), voff_b = piece_voff(8 + (wave & 1));
+    const unsigned dst_a = piece_dst(wave), dst_b = piece_dst(8 + (wave & 1));
+    const unsigned step_a = (unsigned)(KV * (a_is_k ? p.ldk : p.ldv) * 2), step_b = (unsigned)(KV * p.ldv * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_all;
+    auto stage = [&](const int slot) {   // requests the NEXT tile in sequence (offsets advance by one tile per call)
+        const unsigned base = lds0 + (unsigned)(slot * SLOT_BYTES);
+        dma16(rs_a, base + dst_a, voff_a, 0);
+        voff_a += step_a;
+        if (wave < NPIECE - 8) {
+            dma16(rs_v, base + dst_b, voff_b, 0);
+            voff_b += step_b;
+        }
+    };
+    // ---- constants of the ring slots (the DMA never touches them): K chunk 5 and V panel-1 chunk 1 hold {1, 0 x 7}
+    // per key, V panel-1 chunk 2 zeros
+    for (int i = tid; i < NSLOT * 3 * 64; i += 64 * NWV) {
+        const int slot = i / 192, r = i % 192, region = r / 64, key = r % 64;
+        const int off = region == 0 ? NKC * 1024 : K_BYTES + V0_BYTES + region * V1_STRIDE;
+        *reinterpret_cast<uint4*>(lds_all + slot * SLOT_BYTES + off + key * 16) = make_uint4(region == 2 ? 0u : 0x3C00u, 0u, 0u, 0u);
+    }
+
+    // ---- Q fragments (B operand: lane = (query l31, k-half hi), 8 consecutive d per k-step), softmax scale * log2(e) folded in
+    int qrow[RB];
+    f16x8 qf[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        qrow[rb] = qb * QB + wave * (32 * RB) + rb * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + hi * 8;
+            U4H8 t;
+            t.u = make_uint4(0, 0, 0, 0);
+            if (qrow[rb] < p.Nq && d0 < D) t.u = *reinterpret_cast<const uint4*>(qp + (size_t)qrow[rb] * p.ldq + d0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.e[j] = (f16)((float)t.e[j] * p.scale_log2);
+            qf[rb][ks] = t.h;
+        }
+    }
+    f32x16 acc[RB][DB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][i][r] = 0.f;
+    float m_cur[RB] = {0.f, 0.f};   // running max of each query (log2 units), always an fp16-representable value
+
+    const int ntiles = (p.Nk + KV - 1) / KV;
+    // per-lane LDS byte offsets of the operand reads inside a slot
+    const unsigned k_lane = (unsigned)(hi * 1024 + l31 * 16);                                    // + ks * 2048 + kt * 512
+    const unsigned v0_lane = (unsigned)(K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    const int v1c = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);                                   // chunk this lane feeds into the transpose
+    const unsigned v1_lane = (unsigned)(K_BYTES + V0_BYTES + (v1c > 2 ? 2 : v1c) * V1_STRIDE + (4 * hi + ((lane & 15) >> 2)) * 16 + (lane & 1) * 8);
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_h4_ptr;
+    typedef __attribute__((address_space(3))) f16x8* lds_h8_ptr;
+
+    f32x16 st[2][RB];        // scores of the step parities
+    f16x8 pb[2][RB][2];      // probabilities of the step parities: [16-key half of the step]
+    f16x8 kf[KS];            // K fragments of the next Q.K^T
+    s16x4 vf[2][DB][2];      // V fragments of the next P.V: [16-key half][panel][keys +0..3 / +8..11]
+    auto read_k = [&](const unsigned kaddr, const int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *(lds_h8_ptr)(size_t)(kaddr + (unsigned)(ks * 2048 + kt * 512));
+    };
+    auto read_v = [&](const unsigned v0addr, const unsigned v1addr, const int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const lds_h4_ptr b0 = (lds_h4_ptr)(size_t)(v0addr + (unsigned)((kt * 32 + 16 * s) * 64));
+            const lds_h4_ptr b1 = (lds_h4_ptr)(size_t)(v1addr + (unsigned)((kt * 32 + 16 * s) * 16));
+            vf[s][0][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(b0);
+            vf[s][0][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(b0 + 64);   // + 8 keys (s16x4 units: 8 bytes)
+            vf[s][1][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(b1);
+            vf[s][1][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(b1 + 16);
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // S'^T (keys x queries) of both row blocks: consecutive MFMAs alternate between the two independent chains
+    auto qk_chain = [&](f32x16 (&dst)[RB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) dst[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[rb][ks], ks == 0 ? zero16 : dst[rb], 0, 0, 0);
+    };
+    // O^T += V^T P^T
+    auto pv_frags = [&](const f16x8 (&pp)[RB][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                const f16x8 a = __builtin_bit_cast(f16x8, __builtin_shufflevector(vf[s][i][0], vf[s][i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pp[rb][s], acc[rb][i], 0, 0, 0);
+            }
+    };
+    auto mask_keys = [&](f32x16& sc, const int key0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) sc[r] = -INFINITY;
+    };
+    auto row_max = [&](const f32x16& sc) __attribute__((always_inline)) {   // two chains of v_max3_f32
+        float m0 = fmaxf(fmaxf(sc[0], sc[1]), sc[2]), m1 = fmaxf(fmaxf(sc[8], sc[9]), sc[10]);
+        m0 = fmaxf(fmaxf(m0, sc[3]), sc[4]);
+        m1 = fmaxf(fmaxf(m1, sc[11]), sc[12]);
+        m0 = fmaxf(fmaxf(m0, sc[5]), sc[6]);
+        m1 = fmaxf(fmaxf(m1, sc[13]), sc[14]);
+        return fmaxf(fmaxf(m0, m1), fmaxf(sc[7], sc[15]));
+    };
+    // shift the running max of row block rb by (about) delta >= 0: what moves is the fp16 value in Q's spare slot, and the
+    // shift applied everywhere else is the exact difference of the two representable values
+    auto shift_max = [&](const int rb, const float delta) __attribute__((always_inline)) -> float {
+        const float tgt = m_cur[rb] + delta;
+        f16 mh = (f16)tgt;
+        if ((float)mh < tgt) {   // round UP: the applied shift is never smaller than the one asked for (P stays below 2^THR)
+            unsigned short bits = __builtin_bit_cast(unsigned short, mh);
+            bits = (unsigned short)((bits & 0x8000u) ? bits - 1 : bits + 1);
+            mh = __builtin_bit_cast(f16, bits);
+        }
+        const float de = (float)mh - m_cur[rb];
+        m_cur[rb] = (float)mh;
+        if (hi) qf[rb][KS - 1][0] = -mh;   // k-slot D lives in the hi half of the last k-step
+        return de;
+    };
+
+    // One step (32 keys); h = 2 t + P.  MODE 0: steady state; 1: the scores produced here belong to the last tile (key mask);
+    // 2: last step (no Q.K^T, no vote)
+    auto step = [&](auto par, auto mode, const int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(par)::value;
+        constexpr int MODE = decltype(mode)::value;
+        if constexpr (P == 0) {
+            // tile boundary: tile t + 1 has landed (requested a whole tile ago) and becomes visible; every wave is done with
+            // tile t - 2 (its last reads, V of step 2t - 3 ... 2t - 2, were waited for before this barrier) -> its slot takes tile t + 2
+            wait_vmcnt<0>();
+            __syncthreads();
+            if (t + 2 < ntiles) stage((t + 2) & 3);
+        }
+        // V of step h - 1: tile t - 1 second half (P = 0) or tile t first half (P = 1); the very first step multiplies it by
+        // P = 0, so any landed tile will do.  K of step h + 2: tile t + 1, half P.
+        const int vslot = (P == 0 && t > 0) ? ((t - 1) & 3) : (t & 3);
+        // addresses as finished VGPRs: address arithmetic inside the pinned region would sit between the instruction groups
+        unsigned kaddr = lds0 + (unsigned)(((t + 1) & 3) * SLOT_BYTES) + k_lane;
+        unsigned v0addr = lds0 + (unsigned)(vslot * SLOT_BYTES) + v0_lane, v1addr = lds0 + (unsigned)(vslot * SLOT_BYTES) + v1_lane;
+        asm volatile("" : "+v"(kaddr), "+v"(v0addr), "+v"(v1addr));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- matrix stream: Q.K^T of step h + 1 on the K fragments in registers, V fragments of step h - 1 load under it;
+        //      then P.V of step h - 1, the K fragments of step h + 2 load under it
+        if constexpr (MODE != 2) qk_chain(st[P ^ 1]);
+        read_v(v0addr, v1addr, P ^ 1);
+        pv_frags(pb[P ^ 1]);
+        if constexpr (MODE != 2) read_k(kaddr, P);
+        // ---- VALU stream: P(h) = exp2(S'(h)) packed to fp16, then ONE max over both row blocks of S'(h + 1) for the vote
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pb[P][rb][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(st[P][rb][r]);
+        float mx = 0.f;
+        if constexpr (MODE != 2) {
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) mask_keys(st[P ^ 1][rb], (2 * t + P + 1) * 32);
+            }
+            mx = fmaxf(row_max(st[P ^ 1][0]), row_max(st[P ^ 1][1]));
+        }
+        if constexpr (MODE == 0) {
+            // 14 MFMAs; per gap: transcendentals (0x400), plain VALU (0x002: packs, then the max chains once Q.K^T is done), LDS reads (0x100)
+#define VD_GAP(NT, NV, ND)                                                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
+    if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);                  \
+    if (NT) __builtin_amdgcn_sched_group_barrier(0x400, NT, 0);                  \
+    if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            // (measured: this order 247 us; MFMAs in pairs 259-268; bare Q.K^T chain 263; the compiler's own order 257-262)
+            VD_GAP(3, 1, 4) VD_GAP(3, 1, 4) VD_GAP(3, 1, 0) VD_GAP(3, 1, 0) VD_GAP(3, 1, 0) VD_GAP(3, 1, 0)
+            VD_GAP(2, 2, 1) VD_GAP(2, 2, 1) VD_GAP(2, 4, 1) VD_GAP(2, 4, 0) VD_GAP(2, 4, 0) VD_GAP(2, 4, 0) VD_GAP(2, 4, 0) VD_GAP(0, 4, 0)
+#undef VD_GAP
+        }
+        if constexpr (MODE != 2) {
+            // the threshold test needs no cross-lane exchange: `any lane above` is the same vote before and after it
+            if (__any(mx > RESCALE_THR)) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    float mr = row_max(st[P ^ 1][rb]);
+                    mr = fmaxf(mr, __shfl_xor(mr, 32, 64));   // both lanes of a query agree on the shift
+                    const float de = shift_max(rb, fmaxf(mr, 0.f));
+                    const float alpha = __builtin_amdgcn_exp2f(-de);
+                    const f16 ah = (f16)alpha;
+#pragma unroll
+                    for (int i = 0; i < DB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[rb][i][r] *= alpha;
+                    // P(h) is relative to the old m and not accumulated yet; S'(h + 1) was computed against the old m
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pb[P][rb][s2][j] *= ah;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[P ^ 1][rb][r] -= de;
+                }
+            }
+        } else {
+            asm volatile("" ::"v"(pb[P][0][0]), "v"(pb[P][0][1]), "v"(pb[P][1][0]), "v"(pb[P][1][1]));
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    stage(0);
+    // The Q loads are the only VMEM results the compiler tracks: consume them here so its s_waitcnt vmcnt(0) lands before the loop
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[rb][ks]));
+    wait_vmcnt<0>();
+    __syncthreads();   // tile 0 and the slot constants are visible
+    if (ntiles > 1) stage(1);
+    // step "-1": scores of step 0 against m = 0, then the first row max sets m; nothing to accumulate yet (P = 0)
+    read_k(lds0 + k_lane, 0);
+    qk_chain(st[0]);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        mask_keys(st[0][rb], 0);
+        float mr = row_max(st[0][rb]);
+        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        const float de = shift_max(rb, (mr == -INFINITY) ? 0.f : mr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[0][rb][r] -= de;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pb[1][rb][s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    read_k(lds0 + k_lane, 1);
+    int t = 0;
+    for (; t + 2 < ntiles; ++t) {
+        step(P0{}, M0{}, t);
+        step(P1{}, M0{}, t);
+    }
+    if (ntiles >= 2) {
+        step(P0{}, M0{}, t);
+        step(P1{}, M1{}, t);
+        ++t;
+    }
+    step(P0{}, M1{}, t);
+    step(P1{}, M2{}, t);
+    read_v(lds0 + (unsigned)((t & 3) * SLOT_BYTES) + v0_lane, lds0 + (unsigned)((t & 3) * SLOT_BYTES) + v1_lane, 1);
+    pv_frags(pb[1]);
+
+    // ---- normalise and store: lane holds d = i*32 + (r&3) + 8*(r>>2) + 4*hi for its query; the row sum sits in accumulator
+    // row D of panel 1 (local row D % 32 = 8 -> register 4 of the hi = 0 lane)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const float l_tot = __shfl(acc[rb][DB - 1][4], l31, 64);
+        const float inv = (l_tot > 0.f) ? 1.0f / l_tot : 0.f;
+        if (qrow[rb] < p.Nq) {
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = i * 32 + 8 * g + 4 * hi;
+                    if (d0 < D) {
+                        U2H4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o.e[j] = (f16)(acc[rb][i][g * 4 + j] * inv);
+                        *reinterpret_cast<uint2*>(op + (size_t)qrow[rb] * p.ldo + d0) = o.u;
+                    }
+                }
+        }
+    }
+}
+
+template <int D>
+int launch_attn_pipe(AttnArgs a, hipStream_t stream) {
+    a.nqb = (a.Nq + 511) / 512;
+    hipLaunchKernelGGL(attn_pipe_kernel<D>, dim3(a.nqb * a.BH), dim3(512), 0, stream, a);
+    return vd_check_launch("vd_attention_f16");
 }
 
 // ---- single-head attention over a WIDE head (D = 128 / 256 / 512): the AutoencoderKL mid-block AttnBlock
@@ -635,12 +933,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, OUT* 
     for (int i = tid; i < n; i += 256) pr[i] = (OUT)(__expf(sr[i] * scale - mx) * inv);
 }
 
-template <int D, int NWV = 4, bool STAG = false>
+template <int D, int NWV = 4>
 int launch_attn(AttnArgs a, hipStream_t stream) {
     constexpr int QB = 32 * NWV;
     a.nqb = (a.Nq + QB - 1) / QB;
     a.ctx_map = (a.ctx_map && ((a.BH / a.H * a.nqb) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NWV, STAG>), dim3(a.nqb * a.BH), dim3(64 * NWV), 0, stream, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NWV>), dim3(a.nqb * a.BH), dim3(64 * NWV), 0, stream, a);
     return vd_check_launch("vd_attention_f16");
 }
 
@@ -677,11 +975,10 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     }
     switch (D) {
         case 40: {
-            // opt-in (VD_ATTN_STAG=1): the half-blocks half an iteration apart.  Correct (test_attention_staggered_halves) and measured
-            // SLOWER: 274-283 us against 265 isolated, forward unchanged; with one block per CU (pure pairing) 313 us -- the two
-            // waves of a SIMD do not overlap one's softmax with the other's MFMAs any better than two lock-stepped blocks do
-            static const char* st_env = getenv("VD_ATTN_STAG");
-            if (w8) return (st_env && st_env[0] == '1') ? launch_attn<40, 8, true>(a, stream) : launch_attn<40, 8>(a, stream);
+            // long self-attention (64x64 / 96x96 latents): 64 queries per wave, software-pipelined (attn_pipe_kernel);
+            // VD_ATTN_PIPE=0: the serial 8-wave loop
+            static const char* pp_env = getenv("VD_ATTN_PIPE");
+            if (w8) return (pp_env && pp_env[0] == '0') ? launch_attn<40, 8>(a, stream) : launch_attn_pipe<40>(a, stream);
             return launch_attn<40>(a, stream);
         }
         case 64: return launch_attn<64>(a, stream);
