@@ -24,10 +24,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "xattn_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # GEMM: without it the accumulators bounce AGPR<->VGPR (64 reads + 64 writes) every K tile
-               "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # (+ the AMDGPU register-pressure trackers where they were measured: halves ff_chain_kernel's spills, takes
+               # splitk_reduce_stats_kernel<8> from 3 to 5 waves per SIMD; bit-identical outputs, profiles/r05_compiler_flags.txt)
+               "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-use-amdgpu-trackers"],
                "conv_halo.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "ff_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "ff_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "ff_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-use-amdgpu-trackers"],
+               "ff_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-use-amdgpu-trackers"],
                "gemm_row320.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

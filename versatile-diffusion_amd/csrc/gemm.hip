@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
 template <int OCT>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs p, int nsplit) {
     constexpr int LANES = 256 / OCT, RPT = 64 / LANES, COLS = OCT * 8;
-    __shared__ float red[LANES][COLS][2];
+    // partial sums as [column-in-octet i][S | Q][row lane][octet] planes of LANES * OCT (+ 4: the planes start 4 banks apart) words: a
+    // wave's 64 stores of one (i, S|Q) are 64 consecutive words, and the 64 column sums read planes that differ in (i, octet).
+    // (Round 5's red[row lane][column][2] put a wave's stores of one i on TWO banks: 0.56 of this kernel's LDS cycles were conflicts.)
+    constexpr int PLANE = LANES * OCT + 4;
+    __shared__ float red[8 * 2 * PLANE];
     __shared__ float pivot[COLS];
     const VdGemmDesc& d = p.d;
     const EpiCtx e = make_epi(d, 0);
@@ -169,16 +173,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
             S += a0;
             Q += a0 * a0;
         }
-        red[rl][co * 8 + i][0] = S;
-        red[rl][co * 8 + i][1] = Q;
+        red[(i * 2) * PLANE + rl * OCT + co] = S;
+        red[(i * 2 + 1) * PLANE + rl * OCT + co] = Q;
     }
     __syncthreads();
     if (tid < COLS && blockIdx.x * COLS + tid < d.N) {
         float S = 0.f, Q = 0.f;
 #pragma unroll 8
-        for (int l = 0; l < LANES; ++l) {
-            S += red[l][tid][0];
-            Q += red[l][tid][1];
+        for (int l = 0; l < LANES; ++l) {   // column tid = octet tid / 8, element tid % 8
+            S += red[((tid & 7) * 2) * PLANE + l * OCT + (tid >> 3)];
+            Q += red[((tid & 7) * 2 + 1) * PLANE + l * OCT + (tid >> 3)];
         }
         const float mean = pivot[tid] + S / 64.f, m2 = fmaxf(Q - S * S / 64.f, 0.f);
         reinterpret_cast<float2*>(d.out_stats)[(size_t)blockIdx.y * d.N + blockIdx.x * COLS + tid] = make_float2(mean, m2);

@@ -161,10 +161,11 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint  # kept for config compatibility; inference never re-computes
 
-    def forward(self, x, context=None, kv=None, qkv=None, ln1_sums=None, post=None):
+    def forward(self, x, context=None, kv=None, qkv=None, ln1_sums=None, post=None, sync=None):
         """post = (wp [C, C], bp, alpha, res [B, N, C], stat_img_rows): SpatialTransformer.proj_out (+ skip / context mixing) to be
         folded into the block's last launch.  Returns (tensor, True) when it was -- the tensor is then proj_out's output -- else
-        the block output (the caller runs proj_out)."""
+        the block output (the caller runs proj_out).  sync: called right before a launch that reads post's `res` (see
+        SpatialTransformer.forward)."""
         if hip_layers.LN_FOLD:  # the three LayerNorms ride in the q/k/v, q and GEGLU projections (VD_EPI_LNFOLD)
             x = self.attn1(x, res=x, ln=self.norm1, qkv=qkv, ln_sums=ln1_sums)
             C = x.shape[-1]
@@ -188,6 +189,8 @@ class BasicTransformerBlock(nn.Module):
                     wp, bp, alpha, pres, hw = post
                     kw.update(wp=wp, bp=bp, alpha=alpha, res=pres, want_stats=True, stat_img_rows=hw)
                 if kw:
+                    if folded and sync is not None:
+                        sync()
                     out = ops.ff_chain(xin, w1p, b1p, w2, b2, self.norm3.eps, **kw)
                     return (out, True) if folded else out
                 return self.ff(xin, res=xin, ln=self.norm3)
@@ -224,9 +227,11 @@ class SpatialTransformer(nn.Module):
     def project_context(self, context):
         return self.transformer_blocks[0].attn2.project_context(context)
 
-    def forward(self, x, context=None, kv=None, alpha=1.0, res=None):
+    def forward(self, x, context=None, kv=None, alpha=1.0, res=None, sync=None):
         """Returns alpha * (proj_out(...) + bias) + res, res defaulting to x (the block's own skip).
-        alpha/res implement VD's context mixing sum_i r_i * ST_i(x) without extra passes."""
+        alpha/res implement VD's context mixing sum_i r_i * ST_i(x) without extra passes.
+        sync: callable invoked right before the ONE launch that reads `res` (the last of the block): the caller runs the blocks
+        of several context types on forked streams and `res` is the previous type's output (vd.run_unet)."""
         B, H, W, C = x.shape
         blk = self.transformer_blocks[0]
         inner = self.proj_in.out_channels
@@ -243,7 +248,7 @@ class SpatialTransformer(nn.Module):
             if pres.is_contiguous() and self.proj_out.out_channels == inner and self.proj_out.bias is not None:
                 wp, bp = self.proj_out._w()
                 post = (wp, bp, float(alpha), pres.view(B, H * W, C), H * W)
-            h = blk(h, context=context, kv=kv, qkv=qkv, post=post)
+            h = blk(h, context=context, kv=kv, qkv=qkv, post=post, sync=sync)
             if isinstance(h, tuple):   # proj_out (+ skip, alpha, statistics) ran inside the block's last launch
                 out = h[0]
                 st = ops.stats_of(out)
@@ -251,9 +256,13 @@ class SpatialTransformer(nn.Module):
                 if st is not None:
                     out._vd_stats = st
                 return out
+            if sync is not None:
+                sync()
             return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=pres, want_stats=True)
         # norm1's row statistics ride on proj_in's epilogue (ops.gemm(row_sums=...)) instead of a vd_row_stats_f16 launch
         s1 = ops.rowsum_take(B * H * W, x.device) if hip_layers.LN_FOLD else None
         h = self.proj_in(self.norm(x, silu=False), row_sums=s1)
         h = self.transformer_blocks[0](h.view(B, H * W, -1), context=context, kv=kv, ln1_sums=getattr(h, "_vd_rowsums", None))
+        if sync is not None:
+            sync()
         return self.proj_out(h.view(B, H, W, -1), alpha=alpha, res=x if res is None else res, want_stats=True)

@@ -9,6 +9,8 @@ projections can be cached across DDIM steps (`c_info['kv_cache']`, set up by DDI
 """
 from functools import partial
 
+import os
+
 import numpy as np
 import numpy.random as npr
 import torch
@@ -35,6 +37,20 @@ class String_Reg_Buffer(nn.Module):
         return bytes(self.output_string.tolist()).decode()
 
 
+CTX_FORK = os.environ.get("VD_CTX_FORK", "1") != "0"   # development switch: 0 = the context types of a block one after the other
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    """Side streams of the forked context-type branches, one set per device for the whole process: the eager warm-up step and
+    the captured step use the same streams, so the per-stream workspaces of vd_hip.ops (keyed by stream) are allocated once,
+    outside any capture."""
+    lst = _SIDE.setdefault(device.index, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst[:n]
+
+
 def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1, emb_rows=None):
     """Walk i/m/o orders of `data_net` (reference vd.py:352-378 / 429-453).
 
@@ -57,6 +73,21 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     ratios = ratios / ratios.sum()
     hs = []
 
+    def context_kv(module, spec):
+        _, c, _, cache = spec
+        kv = None
+        if cache is not None:
+            kv = cache.get(id(module))
+            stale = cache.get("_stale")
+            if kv is None:
+                kv = module[0].project_context(c)
+                cache[id(module)] = kv
+                cache.setdefault("_modules", {})[id(module)] = module   # lets the sampler refresh K/V without a forward
+            elif stale and id(module) in stale:   # buffer a captured graph reads: new context, same storage
+                kv.copy_(module[0].project_context(c))
+                stale.discard(id(module))
+        return kv
+
     def run_context(h):
         modules = [next(it) for it in c_iters]
         if mixing_type == "layer":
@@ -64,24 +95,44 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
             modules, specs, rs = [modules[pick]], [ctx_specs[pick]], [1.0]
         else:
             specs, rs = ctx_specs, ratios
-        out = None
         single = len(modules) == 1
-        for module, spec, r in zip(modules, specs, rs):
-            _, c, _, cache = spec
-            kv = None
-            if cache is not None:
-                kv = cache.get(id(module))
-                stale = cache.get("_stale")
-                if kv is None:
-                    kv = module[0].project_context(c)
-                    cache[id(module)] = kv
-                    cache.setdefault("_modules", {})[id(module)] = module   # lets the sampler refresh K/V without a forward
-                elif stale and id(module) in stale:   # buffer a captured graph reads: new context, same storage
-                    kv.copy_(module[0].project_context(c))
-                    stale.discard(id(module))
-            # h_out = sum_i r_i * ST_i(h) = sum_i r_i * proj_i + h   (sum r_i = 1): chained through the epilogue
-            out = module(h, None, c, kv=kv, alpha=1.0 if single else float(r), res=out)
-        return out
+        kvs = [context_kv(m, sp) for m, sp in zip(modules, specs)]
+        # h_out = sum_i r_i * ST_i(h) = sum_i r_i * proj_i + h   (sum r_i = 1): chained through the epilogue of each type's LAST
+        # launch (alpha = r_i, res = the previous type's output).  Everything in front of that launch depends on h only, so the
+        # types run as forked branches (side streams; inside the sampler's HIP graph: parallel branches): at the per-GPU batch of
+        # the multi-context workloads one type's launches fill half the chip.  Only the last launches are ordered, by events.
+        if single or not CTX_FORK or not h.is_cuda:
+            out = None
+            for module, spec, kv, r in zip(modules, specs, kvs, rs):
+                out = module(h, None, spec[1], kv=kv, alpha=1.0 if single else float(r), res=out)
+            return out
+        main = torch.cuda.current_stream()
+        sides = _side_streams(h.device, len(modules) - 1)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        outs, done = [], []
+        for i, (module, spec, kv, r) in enumerate(zip(modules, specs, kvs, rs)):
+            st = main if i == 0 else sides[i - 1]
+            prev = outs[-1] if outs else None
+            prev_done = done[-1] if done else None
+            with torch.cuda.stream(st):
+                if i > 0:
+                    st.wait_event(fork)
+                out = module(h, None, spec[1], kv=kv, alpha=float(r), res=prev,
+                             sync=(None if prev_done is None else (lambda e=prev_done, s_=st: s_.wait_event(e))))
+                ev = torch.cuda.Event()
+                ev.record(st)
+            if i > 0:
+                out.record_stream(main)
+                st_ = getattr(out, "_vd_stats", None)   # ChanStats of the block output, written by the branch's last launch
+                if st_ is not None and torch.is_tensor(getattr(st_, "buf", None)):
+                    st_.buf.record_stream(main)
+            outs.append(out)
+            done.append(ev)
+        main.wait_event(done[-1])
+        for ev in done[1:-1]:
+            main.wait_event(ev)
+        return outs[-1]
 
     h = x
     nb = x.shape[0]
