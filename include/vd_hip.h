@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtime_api.h>: plain C hosts need no HIP headers */
 
-#define VD_HIP_ABI_VERSION 7
+#define VD_HIP_ABI_VERSION 8
 #define VD_MAX_SPLIT_K 32
 
 /* ---- epilogue description for vd_gemm_f16 ------------------------------------------------ */
@@ -46,8 +46,8 @@ typedef struct ihipStream_t* hipStream_t; /* same declaration as <hip/hip_runtim
 #define VD_EPI_OUT_F32 16     /* store fp32 instead of fp16                                   */
 #define VD_EPI_LNFOLD 32      /* A rows are LayerNorm'ed on the fly, see VdGemmDesc.colsum     */
 #define VD_EPI_LN_INLOOP 64   /* with VD_EPI_LNFOLD and ln_stats == NULL: row statistics inside the K loop (explicit opt-in) */
-#define VD_EPI_GROUPNORM 128  /* out = [SiLU](GroupNorm(epilogue result)): see VdGemmDesc.gn_gamma; split launches only   */
-#define VD_EPI_GN_SILU 256    /* ... followed by SiLU                                                                      */
+#define VD_EPI_GROUPNORM 128  /* reserved (ABI 5-7: GroupNorm inside the split-K reduce; removed in ABI 8, rejected)              */
+#define VD_EPI_GN_SILU 256    /* reserved, as above                                                                        */
 #define VD_EPI_LN_SUMS 512    /* with VD_EPI_LNFOLD (ABI 6): ln_stats points at the int64 [M][2] fixed-point (sum, sum of squares)
                                * of every A row that a producer launch accumulated through VdGemmDesc.row_sums, instead of fp32
                                * (mean, rstd); the epilogue derives mean / rstd over K with ln_eps */
@@ -107,14 +107,12 @@ typedef struct VdGemmDesc {
                             * [M / R][N][2] = (mean, M2 = sum (x - mean)^2) over blocks of R rows of one image; R =
                             * vd_gemm_stat_rows(desc) (depends on the launch the planner picks; 0 = this launch cannot emit
                             * them: leave out_stats NULL and use vd_chan_stats_f16).  fp16 output, batch 1, N % 8 == 0.     */
-    int32_t stat_img_rows; /* rows of one image for out_stats and VD_EPI_GROUPNORM (partials / groups never mix images);
-                            * 0 = Hout * Wout (M for plain matrices)                                                */
-    int32_t gn_groups;     /* VD_EPI_GROUPNORM: number of groups over the N output channels                           */
-    const void* gn_gamma;  /* VD_EPI_GROUPNORM (ABI 5): fp16 [N] scale / shift of a GroupNorm applied to the epilogue result --  */
-    const void* gn_beta;   /* the output is the NORMALISED tensor (the raw one is never stored).  Only launches that are split  */
-    float gn_eps;          /* over K take it: the kernel that sums the fp32 slabs owns whole (sample, channel-slab) panels,    */
-    int32_t reserved3;     /* computes the exact two-pass statistics of its groups in registers and normalises in place.      */
-                           /* Ask vd_gemm_groupnorm_ok(desc) first; res / out_stats are not combined with it.                 */
+    int32_t stat_img_rows; /* rows of one image for out_stats (partials never mix images); 0 = Hout * Wout (M for plain matrices) */
+    int32_t gn_groups;     /* reserved, must be 0 / NULL / 0 (ABI 5-7: operands of VD_EPI_GROUPNORM, the consuming GroupNorm inside the */
+    const void* gn_gamma;  /* kernel that sums split-K slabs; measured neutral against out_stats + the apply launch and removed in   */
+    const void* gn_beta;   /* ABI 8 -- the fields keep the descriptor layout)                                                       */
+    float gn_eps;
+    int32_t reserved3;
     /* Skip 1x1 convolution folded into a 3x3 convolution (ABI 5): out += W_s [N][skip_c0 + skip_c1] . cat(skip_a0, skip_a1)[pixel]
      * -- ResBlock's `skip_connection(x) + h` (lib/model_zoo/openaimodel.py:238-251,272-274) as extra K of the second conv
      * instead of its own GEMM and a residual round trip.  skip_a0 / skip_a1: fp16 tensors on the OUTPUT grid (row strides
@@ -159,11 +157,6 @@ int vd_gemm_plan(const VdGemmDesc* desc, int* tile_cfg, int* nsplit);
  * read): the halo-resident convolution emits one partial per 256-pixel patch (or per whole small image), gemm_f16_kernel one
  * per min(tile rows, image rows), the split-K reduce one per 64 rows.  *rows = 0: no statistics from this launch. */
 int vd_gemm_stat_rows(const VdGemmDesc* desc, int* rows);
-/* 1 when the launch planned for `desc` (vd_gemm_f16; with conv3x3_wstream != 0: vd_conv3x3_wstream_f16) can take
- * VD_EPI_GROUPNORM: it is split over K and a (sample, slab of whole groups) panel of the output fits one block's registers.
- * Replaces conv -> GroupNorm32 -> SiLU of ResBlock.in_layers[2] / out_layers[0:2] (lib/model_zoo/openaimodel.py:196-200,
- * 230-237,254-274) as: split conv -> ONE kernel that sums the slabs, adds bias + emb, normalises and applies SiLU. */
-int vd_gemm_groupnorm_ok(const VdGemmDesc* desc, int conv3x3_wstream);
 /* 1 when the launch planned for `desc` takes the folded skip 1x1 convolution (skip_a0 / skip_w set): the halo-resident 3x3
  * convolution with 256 x 160 blocks, no upsample, the skip tensors on the output grid. */
 int vd_gemm_skip_ok(const VdGemmDesc* desc);
@@ -214,18 +207,6 @@ int vd_conv3x3_wstream_plan(const VdGemmDesc* desc, int* nsplit);
 int vd_gemm_wstream_plan(const VdGemmDesc* desc, int* nsplit);
 /* Development hook: kernel instance (0 = default) and the grid size the split over chunks aims for (256). Process-global. */
 int vd_conv3x3_wstream_set_variant(int variant, int target_blocks);
-/* The same weights-in-registers main loop for every 3x3 / stride 1 / pad 1 convolution (optional nearest-2x upsample in
- * front, optional two-source concat) whose output grid tiles into 128-pixel patches (4 x 32 or 8 x 16 pixels of one image)
- * and whose output width splits into column tiles of 512 / 384 / 320 / 256 / 128 channels (conv_wreg_kernel.h): a block = 4
- * waves over one patch, each wave 128 pixels x 32 .. 128 channels with its accumulators in AGPRs, weights streamed from the
- * fragment-ordered copy (`w_stream`, as above) straight into registers, the input halo of a 64-channel chunk staged in LDS
- * once.  No split: the fused epilogue of `desc` runs in the kernel (out_stats in partials of 128 rows = one patch); split
- * over chunks (few patches): fp32 slabs + the reduce kernel (partials of 64 rows).  vd_conv3x3_wreg_plan: dry run --
- * *supported, the split factor (size desc->ws with vd_gemm_workspace_bytes for it; set desc->ws non-NULL to allow a split)
- * and the rows per out_stats partial (0: none).  Replaces the reference lines of conv3x3_halo_kernel. */
-int vd_conv3x3_wreg_f16(const VdGemmDesc* desc, const void* w_stream, hipStream_t stream);
-int vd_conv3x3_wreg_plan(const VdGemmDesc* desc, int* supported, int* nsplit, int* stat_rows);
-int vd_conv3x3_wreg_set_blocks(int target_blocks);   /* development hook: grid size the split aims for (256) */
 int vd_gemm_tune_set(int M, int N, int K, int ksize, int epi_class, int tile_cfg, int nsplit);
 int vd_gemm_tune_clear(void);
 

@@ -67,7 +67,7 @@ def test_header_compiles_as_plain_c_and_layout_matches_ctypes(tmp_path):
     assert run.returncode == 0, run.stderr
     lines = run.stdout.strip().splitlines()
     kv = dict(t.split("=") for t in lines[0].split())
-    assert int(kv["abi"]) == int(kv["version_macro"]) == 7
+    assert int(kv["abi"]) == int(kv["version_macro"]) == 8
     assert int(kv["sizeof"]) == ctypes.sizeof(VdGemmDesc)
     for field, key in (("M", "off_M"), ("stride_a", "off_stride_a"), ("colsum", "off_colsum"), ("sync", "off_sync"), ("ln_stats", "off_ln_stats"),
                        ("out_stats", "off_out_stats"), ("stat_img_rows", "off_stat_img_rows"), ("gn_gamma", "off_gn_gamma"),

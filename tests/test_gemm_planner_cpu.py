@@ -46,8 +46,10 @@ def test_round_quantisation_drives_the_split():
         cfg, ns = plan(512, 1280, 11520, ks=3, halo=halo)
         assert cfg in (T128x128, T128x64, T128x64d) and 5 <= ns <= 12
     from vd_hip.loader import lib
-    cfg, ns = plan(512, 1280, 11520, ks=3, halo=11)
-    assert cfg == NCFG + 10 and lib().vd_gemm_config_name(cfg) == b"conv3x3_halo_kernel<128,32,32,32,256,4>"
+    # development variants of the halo kernel (whole-K small-M blocks, other barrier placements, ...) are no longer instantiated
+    for removed in (1, 2, 4, 5, 7, 8, 9, 10, 11, 12):
+        assert lib().vd_conv_halo_set_variant(removed) != 0
+    assert lib().vd_conv_halo_set_variant(-1) == 0
 
 
 def test_halo_kernel_takes_the_3x3_convolutions():
@@ -200,35 +202,6 @@ def test_which_launches_emit_groupnorm_statistics():
     assert stat_rows(8192, 1920, 640, flags=32, colsum=True) == 0
 
 
-def test_wreg_column_tiling_covers_the_output_widths():
-    """vd_conv3x3_wreg_plan (dry run): which output widths the weights-in-registers conv tiles into 512 / 384 / 320 / 256 / 128
-    column tiles, split factor and statistics partial for the UNet's 3x3 shapes."""
-    from vd_hip.loader import VdGemmDesc, lib
-
-    def plan(B, H, C, N, ws=True):
-        d = VdGemmDesc()
-        d.M, d.N, d.K = B * H * H, N, 9 * C
-        d.a0 = d.w = d.out = 16
-        d.Hin = d.Win = d.Hout = d.Wout = H
-        d.ksize, d.stride, d.pad, d.c0 = 3, 1, 1, C
-        d.stat_img_rows = H * H
-        d.ws = 16 if ws else None
-        sup, ns, rows = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
-        assert lib().vd_conv3x3_wreg_plan(ctypes.byref(d), ctypes.byref(sup), ctypes.byref(ns), ctypes.byref(rows)) == 0
-        return sup.value, ns.value, rows.value
-
-    for N in (128, 256, 320, 384, 448, 512, 576, 640, 768, 1280, 2560):
-        assert plan(8, 64, 64, N)[0] == 1, N
-    for N in (64, 192, 96):          # 64 and 192 have no tiling, 96 is not a multiple of 64
-        assert plan(8, 64, 64, N)[0] == 0, N
-    assert plan(8, 64, 320, 320) == (1, 1, 128)     # 256 patches x one (3,2) tile: no split, one partial per patch
-    assert plan(8, 32, 640, 640) == (1, 2, 64)      # 64 patches x 2 tiles: split 2, statistics from the reduce kernel
-    sup, ns, rows = plan(8, 16, 1280, 1280)
-    assert sup == 1 and 4 <= ns <= 6 and rows == 64  # 16 patches x 3 tiles
-    assert plan(8, 16, 1280, 1280, ws=False)[1] == 1 # no workspace: no split
-    assert plan(8, 24, 64, 320)[0] == 0              # 24 x 24 grid does not tile into 128-pixel patches
-
-
 def test_which_convolutions_take_the_folded_skip_convolution():
     """vd_gemm_skip_ok: ResBlock's skip 1x1 convolution rides as extra K of the second 3x3 conv where the halo-resident kernel
     takes the launch (its SKIP instance, variant 12); the 8x8 level and the upsampling / strided convs do not -- there the caller
@@ -318,7 +291,6 @@ def test_which_8x8_convolutions_run_without_a_split_and_which_launches_take_row_
     assert conv8(4, 1280) == 20                                 # 80 whole-K tiles < 128: 10 split-kernel tiles, one chunk per split
     assert conv8(8, 1280, split=5) == 5                         # an explicit split factor is honoured
     assert conv8(8, 128) == 2                                   # 2 chunks: below the whole-K kernel's pipeline depth
-    assert conv8(8, 1280, flags=128) == 10                      # VD_EPI_GROUPNORM lives in the reduce kernel
     monkeypatch.setenv("VD_WSK", "0")
     assert conv8(8, 1280) == 10
 

@@ -24,7 +24,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(PROTOTYPES), (declared ^ set(PROTOTYPES))
     for name in declared:
         assert hasattr(h, name), name
-    assert h.vd_abi_version() == 7
+    assert h.vd_abi_version() == 8
     # argument validation works without a device
     from vd_hip.loader import VdGemmDesc
     d = VdGemmDesc()

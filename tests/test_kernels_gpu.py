@@ -533,8 +533,11 @@ def test_gemm_every_tile_configuration(ops, dev):
     n = lib().vd_gemm_num_configs()
     assert n >= 8
     try:
+        built = 0
         for cfg in range(n):
-            ops.gemm_set_override(cfg)
+            if lib().vd_gemm_set_override(cfg) != 0:   # slot of a removed development tile
+                continue
+            built += 1
             name = ops.gemm_kernel_name(cfg)
             out = ops.conv2d_nhwc(x0, pack_conv_weight(wt), bias, x1=x1, rowvec=rv, rows_per_batch=H * W)
             assert rel_l2(out, ref_conv) < 2e-3, name
@@ -546,6 +549,7 @@ def test_gemm_every_tile_configuration(ops, dev):
             assert rel_l2(out, ref_ln) < 3e-3, name
             out = ops.gemm(xg, wgp, bias=bgp, act=ops.ACT_GEGLU)
             assert rel_l2(out, ref_geglu) < 2e-3, name
+        assert built >= 9
     finally:
         ops.gemm_set_override(-1)
 
@@ -576,7 +580,7 @@ def test_gemm_split_k_in_kernel_fixup_equals_reduce_kernel(ops, dev, shape):
     bias, res = rnd((N,), dev, 0.5, 33), rnd((M, N), dev, 1.0, 34)
     ref = a.float() @ w.float().t() + bias.float() + res.float()
     try:
-        for cfg in (-1, 0, 1, 2, 3, 4, 7, 14, 15, 24):
+        for cfg in (-1, 0, 1, 2, 3, 4, 7, 13, 14, 15):
             ops.gemm_set_override(cfg)
             two = ops.gemm(a, w, bias=bias, res=res, split_k=split, fixup=False)
             assert rel_l2(two, ref) < 2e-3, cfg
@@ -703,18 +707,12 @@ def test_conv3x3_halo_every_variant(ops, dev, case):
     if rs:
         kw.update(res=res)
     wp = pack_conv_weight(wt)
-    keep = ops.HALO_FIXUP
     try:
-        for fixup in (False, True):      # channel-chunk split: slabs + reduce kernel / ticketed in-kernel reduction
-            ops.HALO_FIXUP = fixup
-            for v in [-1] + list(range(0, 13)):
-                assert lib().vd_conv_halo_set_variant(v) == 0
-                out = ops.conv2d_nhwc(x, wp, b, **kw)
-                assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, (v, fixup)
-            for rep in range(3):          # the counters re-arm: repeated launches stay correct
-                assert rel_l2(ops.conv2d_nhwc(x, wp, b, **kw), ref) < 2e-3, (rep, fixup)
+        for v in (-1, 0, 3, 6, 13):   # planner / off (gemm_f16_kernel) / the three instantiated variants (v - 1 = 2, 5, 12)
+            assert lib().vd_conv_halo_set_variant(v) == 0
+            out = ops.conv2d_nhwc(x, wp, b, **kw)
+            assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, v
     finally:
-        ops.HALO_FIXUP = keep
         lib().vd_conv_halo_set_variant(-1)
 
 
@@ -1287,11 +1285,6 @@ def test_conv3x3_wstream(ops, dev, case, monkeypatch):
         o1 = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw1)
         assert rel_l2(o1, ref - kw["rowvec"].float().view(B, 1, 1, Co) + kw["rowvec"][:1].float().view(1, 1, 1, Co)) < 2e-3
     monkeypatch.setenv("VD_WSK", "0")   # the split kernel + reduce launch
-    monkeypatch.setenv("VD_WSTREAM_IPB", "4")   # its 4-images-per-block geometry (opt-in; taken where B % 4 == 0 and N % 128 == 0)
-    out4 = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
-    assert rel_l2(out4, ref) < 2e-3
-    _stats_close(ops.stats_of(out4), _chan_stats_ref(out4.view(B, 64, Co), B, 1), 64)
-    monkeypatch.delenv("VD_WSTREAM_IPB")
     try:
         for var in range(4):
             for target in (256, 64, 1024):
@@ -1382,114 +1375,6 @@ def test_blocks_are_placed_round_robin_over_the_xcds(ops, dev):
         assert torch.equal(ids, ids[0:1].expand(gy, gx)), "splits of a tile run on different XCDs"
         rot = (ids[0] - torch.arange(gx)) % 8
         assert bool((rot == rot[0]).all()), "placement is not round-robin in block order"
-
-
-@pytest.mark.parametrize("case", [
-    # B, H, W, c0, c1, Co, ups, rowvec, residual
-    (8, 64, 64, 320, 0, 320, 0, True, False),      # 64x64 level, one (3,2) column tile, 256 patches: fused epilogue
-    (2, 64, 64, 64, 64, 320, 0, False, True),      # concat, residual; 64 patches: split over chunks + reduce
-    (4, 32, 32, 128, 0, 640, 0, True, True),       # column tiles (3,3) + (2,2)
-    (2, 16, 16, 128, 0, 640, 1, False, False),     # Upsample conv: 16x16 -> 32x32
-    (4, 16, 16, 256, 0, 1280, 0, False, True),     # 8 x 16 pixel patches, column tiles (4,4) (4,4) (2,2)
-    (8, 16, 16, 64, 0, 512, 0, True, False),       # one (4,4) tile
-    (1, 96, 96, 64, 0, 320, 0, True, False),       # 768x768 geometry
-    (2, 32, 32, 64, 0, 128, 0, False, False),      # (1,1) tile (VAE width)
-    (8, 32, 32, 64, 64, 384, 0, False, True),      # one (3,3) tile, no split
-    (2, 32, 32, 64, 0, 192, 0, False, False),      # width without a column tiling: stays on the halo kernel
-])
-def test_conv3x3_wreg(ops, dev, case, monkeypatch):
-    """vd_conv3x3_wreg_f16 (weights in registers, 128-pixel patches, every wave layout, fused epilogue and split + reduce)
-    against torch's fp32 convolution; per-channel statistics of the stored output against chan_stats of it."""
-    from vd_hip.loader import lib
-    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
-    monkeypatch.setattr(ops, "WREG", True)
-    B, H, W, c0, c1, Co, ups, rv, rs = case
-    x = rnd((B, H, W, c0), dev, 1.0, 500)
-    x1 = rnd((B, H, W, c1), dev, 1.0, 501) if c1 else None
-    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.04, 502)
-    b = rnd((Co,), dev, 0.3, 503)
-    Hv, Wv = H << ups, W << ups
-    ref = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, ups)
-    kw = dict(ksize=3, pad=1, ups=ups, x1=x1)
-    if rv:
-        rowvec = rnd((B, Co), dev, 0.5, 504)
-        kw.update(rowvec=rowvec, rows_per_batch=Hv * Wv)
-        ref = ref + rowvec.float().view(B, 1, 1, Co)
-    if rs:
-        res = rnd((B, Hv, Wv, Co), dev, 1.0, 505)
-        kw.update(res=res)
-        ref = ref + res.float()
-    wp, wsm = pack_conv_weight(wt), pack_conv_weight_stream(wt)
-    try:
-        for target in (256, 64, 2048):   # no split / fewer blocks / deep split
-            assert lib().vd_conv3x3_wreg_set_blocks(target) == 0
-            out = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, **kw)
-            assert out.shape == ref.shape and rel_l2(out, ref) < 2e-3, target
-            outs = ops.conv2d_nhwc(x, wp, b, w_stream=wsm, want_stats=True, **kw)
-            assert rel_l2(outs, ref) < 2e-3, target
-            st = ops.stats_of(outs)
-            assert st is not None and st.HW == Hv * Wv and st.C == Co
-            R = Hv * Wv // st.T
-            o3 = outs.view(B, Hv * Wv, Co)
-            if R == 128 and Co != 192:   # the kernel's own epilogue: a partial is a 128-pixel PATCH (4 x 32 or 8 x 16 pixels)
-                tw = 32 if Wv % 32 == 0 else 16
-                th = 128 // tw
-                o = outs.view(B, Hv // th, th, Wv // tw, tw, Co).permute(0, 1, 3, 2, 4, 5).reshape(B * st.T, 128, Co)
-                refst = torch.stack([o.double().mean(1), ((o.double() - o.double().mean(1, keepdim=True)) ** 2).sum(1)], -1).float()
-                _stats_close(st, refst, R)
-            elif R == 64:
-                _stats_close(st, _chan_stats_ref(o3, B, st.T), R)
-            gamma, beta = rnd((Co,), dev, 0.5, 506) + 1.0, rnd((Co,), dev, 0.5, 507)
-            refn = F.silu(F.group_norm(o3.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
-            assert rel_l2(ops.groupnorm_from_stats(o3, gamma, beta, st, groups=32, eps=1e-5, silu=True), refn) < 2e-3
-    finally:
-        lib().vd_conv3x3_wreg_set_blocks(256)
-
-
-@pytest.mark.parametrize("case", [
-    # B, H, c0, c1, Co, silu, eps, expect fused
-    (8, 32, 640, 0, 640, True, 1e-5, True),       # 32x32 level: halo conv split 2 -> reduce + GroupNorm in one kernel (960 threads)
-    (8, 16, 1280, 0, 1280, True, 1e-5, True),     # 16x16 level: split 4
-    (8, 16, 1280, 640, 1280, False, 1e-6, True),  # concat input, no SiLU
-    (8, 8, 1280, 0, 1280, True, 1e-5, True),      # 8x8 level: weight-streaming conv
-    (2, 32, 128, 0, 320, True, 1e-5, None),       # 10 channels per group (slab unit 20); split or not is the planner's call
-    (8, 64, 320, 0, 320, True, 1e-5, False),      # one block per CU, no split: the conv returns the raw output + statistics
-])
-def test_conv_groupnorm_fused_in_the_reduce(ops, dev, case, monkeypatch):
-    """VD_EPI_GROUPNORM: conv (+ bias + per-image row vector) -> GroupNorm -> SiLU where the conv is split over K -- the
-    reduce kernel holds a (sample, slab of groups) panel in registers, two-pass statistics, normalised output only; against
-    torch (conv fp32 -> group_norm -> silu) and against the unfused chain of this library."""
-    from vd_hip.pack import pack_conv_weight, pack_conv_weight_stream
-    monkeypatch.setattr(ops, "GN_REDUCE", True)   # opt-in path
-    B, H, c0, c1, Co, silu, eps, expect = case
-    x = rnd((B, H, H, c0), dev, 1.0, 600)
-    x1 = rnd((B, H, H, c1), dev, 1.0, 601) if c1 else None
-    wt = rnd((Co, c0 + c1, 3, 3), dev, 0.03, 602)
-    b = rnd((Co,), dev, 0.3, 603)
-    rowvec = rnd((B, Co), dev, 0.5, 604)
-    gamma, beta = rnd((Co,), dev, 0.5, 605) + 1.0, rnd((Co,), dev, 0.5, 606)
-    conv = _conv_ref(torch.cat([x, x1], -1) if c1 else x, wt, b, 1, 1, 0) + rowvec.float().view(B, 1, 1, Co)
-    ref = F.group_norm(conv.permute(0, 3, 1, 2), 32, gamma.float(), beta.float(), eps).permute(0, 2, 3, 1)
-    if silu:
-        ref = F.silu(ref)
-    wp = pack_conv_weight(wt)
-    kw = dict(ksize=3, pad=1, x1=x1, rowvec=rowvec, rows_per_batch=H * H)
-    if H == 8:
-        kw["w_stream"] = pack_conv_weight_stream(wt)
-    out = ops.conv2d_nhwc(x, wp, b, want_stats=True, gn=(gamma, beta, 32, eps, silu), **kw)
-    fused = bool(getattr(out, "_vd_normalized", False))
-    assert expect is None or fused == expect
-    if fused:
-        assert ops.stats_of(out) is None
-        assert rel_l2(out, ref) < 2e-3
-        assert torch.equal(out, ops.conv2d_nhwc(x, wp, b, gn=(gamma, beta, 32, eps, silu), **kw))   # run-to-run identical
-    else:
-        assert rel_l2(out, conv) < 2e-3 and ops.stats_of(out) is not None
-    raw = ops.conv2d_nhwc(x, wp, b, want_stats=True, **kw)
-    chain = ops.groupnorm_silu(raw, gamma, beta, groups=32, eps=eps, silu=silu)
-    assert rel_l2(chain, ref) < 2e-3
-    if fused:
-        assert rel_l2(out, chain) < 2e-3
 
 
 @pytest.mark.parametrize("case", [

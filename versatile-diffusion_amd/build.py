@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # VD_BUILD_OUT: development builds of variants (VD_EXTRA_DEFS) next to the product library, for VD_HIP_LIB A/B runs
 OUT = os.environ.get("VD_BUILD_OUT") or os.path.join(HERE, "libvd_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "conv_halo.hip", "conv_halo_big.hip", "conv_wstream.hip", "ff_fused.hip", "ff_chain.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
+SOURCES = ["gemm.hip", "conv_halo.hip", "conv_wstream.hip", "ff_fused.hip", "ff_chain.hip", "gemm_row320.hip", "norm.hip", "gn_fused.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "preprocess.hip", "lowrank.hip"]
 # every header under csrc/ (a kernel header that is not hashed would let a stale library pass the stamp check)
 import glob
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "vd_hip.h")]

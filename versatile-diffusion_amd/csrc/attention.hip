@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 8 ? VD_ATTN_W8_MINW : (D <= 64 &&
             // an XCD owns BH / 8 CONSECUTIVE (batch, head) pairs (round 5; before: pairs xcd, xcd + 8, ... = one head of every
             // sample): the heads of a token are neighbours in memory (D * 2 = 80 .. 320 bytes each inside the fused q|k|v row),
             // so consecutive pairs share the 128-byte lines of K / V / q / out inside ONE L2 instead of pulling every line into
-            // two of them (counter traffic of the D = 40 launch: 2.1x the unique bytes).  VD_ATTN_PAIRMAP=0: the old interleave.
+            // two of them (counter traffic of the D = 40 launch: 2.1x the unique bytes).
             const int xcd = bid & 7, idx = bid >> 3;
             bh = p.pair_contig ? xcd * (p.BH >> 3) + idx / p.nqb : xcd + 8 * (idx / p.nqb);
             qb = idx % p.nqb;
@@ -961,12 +961,9 @@ extern "C" int vd_attention_f16(const void* q, const void* k, const void* v, voi
     a.causal = causal;
     a.nqb = 0;   // set by the launcher (queries per block depend on the instantiation)
     a.BH = B * H;
-    static const char* ctx_env = getenv("VD_ATTN_CTXMAP");   // development switch: 0 = always the K/V-locality mapping
-    a.ctx_map = (Nk <= 2 * KV && !(ctx_env && ctx_env[0] == '0')) ? 1 : 0;
-    static const char* pm_env = getenv("VD_ATTN_PAIRMAP");   // development switch: 0 = pairs interleaved over the XCDs (rounds 1-4)
-    a.pair_contig = (pm_env && pm_env[0] == '0') ? 0 : 1;
-    static const char* w8_env = getenv("VD_ATTN_W8");        // development switch: 0 = always 4 waves per block
-    const bool w8 = !(w8_env && w8_env[0] == '0') && causal == 0 && Nq >= 2048 && Nk >= 1024;
+    a.ctx_map = (Nk <= 2 * KV) ? 1 : 0;
+    a.pair_contig = 1;
+    const bool w8 = causal == 0 && Nq >= 2048 && Nk >= 1024;
     if (H == 1 && (D == 128 || D == 256 || D == 512)) {   // one wide head: head dim split over the waves of a block
         VD_REQUIRE(causal == 0, "vd_attention_f16: the wide single-head kernel has no causal mask");
         if (D == 128) return launch_attn_wide<128>(a, stream);

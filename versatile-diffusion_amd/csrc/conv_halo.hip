@@ -30,7 +30,7 @@ int halo_setting() {
     if (v == -2) {
         const char* e = getenv("VD_CONV_HALO");
         v = e ? atoi(e) : -1;
-        if (v < -1 || v > VD_CONV_HALO_VARIANTS) v = -1;
+        if (v < -1 || v > VD_CONV_HALO_VARIANTS || (v > 0 && !(v - 1 == 2 || v - 1 == 5 || v - 1 == 12))) v = -1;
         g_halo_variant.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -94,8 +94,14 @@ bool halo_geometry(const GemmArgs& a, int BM, ConvHaloArgs& c) {
 
 }  // namespace
 
+// Instantiated: variants 2 (256 x 160 blocks, pinned mid-barrier loop: every UNet width), 5 (256 x 128: the VAE widths) and 12 (2 with
+// the folded skip convolution).  The other table slots were development variants (barrier placements 0 / 1 / 3, one wave per SIMD,
+// whole-K small-M blocks, 128-pixel patches) that lost their in-forward A/Bs (profiles/HISTORY.md); removed in round 6.
+static bool halo_built(int variant) { return variant == 2 || variant == 5 || variant == 12; }
+
 extern "C" int vd_conv_halo_set_variant(int v) {
     VD_REQUIRE(v >= -1 && v <= VD_CONV_HALO_VARIANTS, "vd_conv_halo_set_variant: %d out of range", v);
+    VD_REQUIRE(v <= 0 || halo_built(v - 1), "vd_conv_halo_set_variant: variant %d is not instantiated", v - 1);
     g_halo_variant.store(v, std::memory_order_relaxed);
     return VD_OK;
 }
@@ -123,11 +129,6 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
         if (d.N % 160 == 0) v = 2;
         else if (d.N % 128 == 0) v = 5;
         else return 0;
-        // experiment (VD_CONV_HALO128=1): where 256-pixel patches x column tiles cover less than the chip (the 32x32 and
-        // 16x16 levels: 128 / 64 tiles, split 2 / 4 over the channel chunks), 128-pixel patches on four waves double the
-        // tiles instead of the split
-        static const char* h128_env = getenv("VD_CONV_HALO128");
-        if (v == 2 && h128_env && h128_env[0] == '1' && (long)(d.M / 256) * (d.N / 160) < 256) v = 11;
     }
     const HaloVariant& hv = kHalo[v];
     ConvHaloArgs& c = *static_cast<ConvHaloArgs*>(conv_args);
@@ -137,27 +138,10 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
     if (2 * c.halo_bytes + wst * (hv.mode == 4 ? 9 : 1) * hv.bn * 128 > 160 * 1024) return 0;
     const long tiles = (long)c.g.tiles_m * c.g.tiles_n;
     if (setting < 0 && tiles < 32) {
-        // 8x8-level layers: too few 256-pixel patches; they stay on gemm_f16_kernel with a deep split over K.  Opt-in
-        // (VD_CONV_SMALLM=1, or forced as variant 10): 128-pixel patches (two 8x8 images) x 32 output channels with the whole K
-        // range in one block -- no fp32 slabs, no reduce launch, every weight byte fetched by one XCD.  Measured (session Z):
-        // 44 us instead of 43 + the reduce launch for M = 512, N = 1280, K = 11520, 80 instead of 59 + reduce at K = 23040,
-        // and the graph-replayed forward is 0.09 ms SLOWER: 160 blocks of four waves with 32 x 32 wave tiles pay two
-        // ds_read_b128 per MFMA and ~17 LDS-DMA requests per wave and chunk in ONE instruction stream per SIMD (2.2 us per
-        // chunk where the MFMAs need 0.6).
-        static const char* sm_env = getenv("VD_CONV_SMALLM");
-        if (!(sm_env && sm_env[0] == '1')) return 0;
-        const HaloVariant& sv = kHalo[10];
-        if (d.N % sv.bn != 0 || !halo_geometry(a, sv.bm, c)) return 0;
-        c.g.tiles_n = d.N / sv.bn;
-        if (2 * c.halo_bytes + 3 * 9 * sv.bn * 128 > 160 * 1024) return 0;
-        c.chunks_per_split = c.nchunks;
-        *variant_out = 10;
-        *nsplit_out = (d.split_k > 1 && can_split) ? d.split_k : 1;
-        if (*nsplit_out > 1) {
-            c.chunks_per_split = (c.nchunks + *nsplit_out - 1) / *nsplit_out;
-            *nsplit_out = (c.nchunks + c.chunks_per_split - 1) / c.chunks_per_split;
-        }
-        return 1;
+        // 8x8-level layers: too few 256-pixel patches; they go to the weight-streaming kernels (conv_wstream.hip) or stay on
+        // gemm_f16_kernel with a deep split over K.  (A whole-K small-M instance of this kernel -- 128-pixel patches x 32 channels --
+        // measured 0.09 ms per forward slower, round 4; removed.)
+        return 0;
     }
     // split over channel chunks until one round of blocks covers the chip; unit = one tap of one block
     int ns = 1;
@@ -197,22 +181,15 @@ int vd_conv_halo_plan(const void* gemm_args, int can_split, void* conv_args, int
     return 1;
 }
 
-int vd_conv_halo_launch_big(const void* conv_args, int variant, int nsplit, hipStream_t stream);
 
 int vd_conv_halo_launch(const void* conv_args, int variant, int nsplit, hipStream_t stream) {
     const ConvHaloArgs& c = *static_cast<const ConvHaloArgs*>(conv_args);
     switch (variant) {
-        case 0: return launch_conv_halo<256, 160, 32, 160, 512, 0>(c, nsplit, stream);
-        case 1: return launch_conv_halo<256, 160, 32, 160, 512, 1>(c, nsplit, stream);
         case 2: return launch_conv_halo<256, 160, 32, 160, 512, 2>(c, nsplit, stream);
-        case 3: return launch_conv_halo<256, 128, 64, 64, 512, 0>(c, nsplit, stream);
-        case 4: return launch_conv_halo<256, 128, 64, 64, 512, 1>(c, nsplit, stream);
         case 5: return launch_conv_halo<256, 128, 64, 64, 512, 2>(c, nsplit, stream);
-        case 8: return launch_conv_halo<256, 160, 32, 160, 512, 3>(c, nsplit, stream);
-        case 9: return launch_conv_halo<256, 128, 64, 64, 512, 3>(c, nsplit, stream);
-        case 10: return launch_conv_halo<128, 32, 32, 32, 256, 4>(c, nsplit, stream);
-        case 11: return launch_conv_halo<128, 160, 32, 160, 256, 2>(c, nsplit, stream);
         case 12: return launch_conv_halo<256, 160, 32, 160, 512, 2, true>(c, nsplit, stream);
-        default: return vd_conv_halo_launch_big(conv_args, variant, nsplit, stream);
+        default:
+            vd_set_error("conv3x3_halo: variant %d is not instantiated", variant);
+            return VD_ERR_UNSUPPORTED;
     }
 }

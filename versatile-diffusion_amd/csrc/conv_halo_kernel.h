@@ -20,10 +20,11 @@
 //     (2.2 x larger) plain tile would need, and BM can be 256 pixels at BN = 160: N = 320 / 640 / 1280 are covered without
 //     padding columns and a 64x64-latent conv is exactly one block per CU.
 //   * the halo of the NEXT chunk arrives in 1-KiB pieces spread over the taps of the current one (double-buffered).
-//   * MODE 0: one barrier at the top of every tap (wait for the tap's weight tile, issue the next), 2 weight stages.
-//     MODE 1: the barrier sits in the MIDDLE of a tap, 3 weight stages, and operand fragments are requested one k-step ahead
-//     with two named register sets -- nothing a wave needs right after the barrier depends on it (the second half of the
-//     tap reads a stage published by the previous barrier), so the matrix pipe does not drain at tap boundaries.
+//   * the barrier of a tap sits in the MIDDLE of it, 3 weight stages, and operand fragments are requested one k-step ahead
+//     with two named register sets, the request / MFMA order pinned with sched_barrier -- nothing a wave needs right after
+//     the barrier depends on it (the second half of the tap reads a stage published by the previous barrier), so the matrix
+//     pipe does not drain at tap boundaries.  (MODE 2 of rounds 3-5; the other barrier placements -- top of the tap, unpinned,
+//     DMA requests spread over the MFMA gaps, one barrier per chunk -- lost in the forward and were removed in round 6.)
 //   * split-K runs over channel chunks (fp32 slabs + splitk_reduce_kernel of gemm.hip).
 // Epilogue (bias / activation / alpha in registers, tile staged through LDS, 16-byte row segments + per-image row vector +
 // residual on the way out) follows gemm_f16_kernel; output rows are mapped from patch order back to pixel order.
@@ -60,7 +61,7 @@ struct ConvHaloArgs {
 #define HALO_ABL(p, k) false
 #endif
 
-// MODE 0 / 1 as above.  NT = 64 * waves; wave grid (BM / WM) x (BN / WN), wave tile WM pixels x WN channels.
+// MODE: 2 (the only main loop left, see above).  NT = 64 * waves; wave grid (BM / WM) x (BN / WN), wave tile WM pixels x WN channels.
 // SKIP (round 4): behind the 3x3 chunks the block multiplies the chunks of a 1x1 convolution of a second (two-source) input on
 // the same pixels into the same accumulators -- ResBlock's skip_connection(x) + h as extra K of the second conv (d.skip_*).
 template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>
@@ -71,12 +72,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == NW, "waves must tile the block");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr bool CHUNKW = MODE == 4;                  // MODE 4: a weight stage holds all 9 tap tiles of a chunk, one barrier per chunk
-    constexpr int WST = MODE == 0 ? 2 : 3;              // weight stages
-    constexpr bool PIN = MODE == 2 || MODE == 3;        // MODE 2: MODE 1 with the request / MFMA order pinned (sched_barrier)
-    constexpr bool SPREAD = MODE == 3;                  // MODE 3: MODE 2 with the LDS-DMA requests of a tap issued one per MFMA gap
+    static_assert(MODE == 2, "one main loop: mid-tap barrier, three weight stages, pinned request order");
     constexpr int WTILE = BN * 128;                     // bytes of one weight tile [BN][64]
-    constexpr int WSTAGE = CHUNKW ? 9 * WTILE : WTILE;
+    constexpr int WSTAGE = WTILE;
     constexpr int NPW = BN / 8;                         // 1-KiB DMA pieces (8 rows) of a weight tile
     constexpr int WPW = (NPW + NW - 1) / NW;            // ... per wave
     constexpr int HPXMAX = BM * 100 / 64 + 16;          // bound on halo pixels (checked by the launcher)
@@ -197,13 +195,6 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         }
     };
 
-    auto issue_w_piece = [&](auto jt, int c, int tap, int stage) {   // piece j of the weight tile of (chunk c, tap)
-        constexpr int j = decltype(jt)::value;
-        if (!dma_on) return;
-        const int q = j * NW + wave_s;
-        if (q < NPW) dma16(ws_w, w_lds0 + (unsigned)(stage * WSTAGE + (CHUNKW ? tap * WTILE : 0) + q * 1024), wvoff[j], (unsigned)((tap * ctot + c * 64) * 2));
-    };
-
     // acc[i][j]: TRANSPOSED 32x32 sub-tile (MFMA A operand = weight rows, B operand = pixels): a lane owns output pixel
     // l31 of fragment i and, per register group g = r >> 2, channels 8g + 4hi + (r & 3) of fragment j.
     f32x16 acc[MI][NI];
@@ -271,117 +262,12 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
     {
         const ChunkSrc cs0 = chunk_src(c_begin);
         static_for<0, MAXHP>([&](auto jt) { issue_halo(jt, cs0, lds0); });
-        if constexpr (CHUNKW) {
-            static_for<0, 9>([&](auto tt) {
-                static_for<0, WPW>([&](auto jt) { issue_w_piece(jt, c_begin, decltype(tt)::value, 0); });
-            });
-            if (ncl > 1) {
-                static_for<0, 9>([&](auto tt) {
-                    static_for<0, WPW>([&](auto jt) { issue_w_piece(jt, c_begin + 1, decltype(tt)::value, 1); });
-                });
-            }
-        } else {
-            issue_w(c_begin, 0, 0);
-            if constexpr (MODE != 0) issue_w(c_begin, 1, 1);
-        }
+        issue_w(c_begin, 0, 0);
+        issue_w(c_begin, 1, 1);
     }
 
     if (HALO_ABL(p, 3)) dma_on = false;
-    if constexpr (CHUNKW) {
-        // ---- small-M layers (8x8 images: a handful of patches, the weight stream is everything): narrow column tiles, the
-        // whole K range in one block (no split-K slabs), ONE barrier per chunk, three weight stages of 9 tap tiles each.
-        // While chunk lc is multiplied, the halo of chunk lc + 1 (L2-resident activations) is requested behind its first
-        // k-steps and the weight tiles of chunk lc + 2 (HBM) behind the following ones, one piece per k-step (a wave has its
-        // SIMD to itself here: a burst of requests would idle the matrix pipe for its whole issue time).  The wait at the top
-        // of a chunk is counted: the weight pieces requested during the previous chunk -- always the youngest -- stay in flight,
-        // so weights have two chunks of time to arrive from HBM.
-        constexpr int WMIN = 9 * (NPW / NW);          // weight pieces EVERY wave issues per chunk
-        constexpr int NREQ = MAXHP + 9 * WPW;         // request slots per chunk: halo pieces first, then weight pieces
-        static_assert(NREQ <= 36 && WMIN < 64, "one request per k-step");
-        int stg = 0;                                  // lc % 3
-        for (int lc = 0; lc < ncl; ++lc) {
-            const int c = c_begin + lc;
-            const int halo_off = (lc & 1) * p.halo_bytes;
-            const unsigned nxt_halo = lds0 + (unsigned)(((lc & 1) ^ 1) * p.halo_bytes);
-            const bool more = lc + 1 < ncl, more2 = lc + 2 < ncl;
-            const ChunkSrc csn = chunk_src(more ? c + 1 : c);
-            const int stg2 = stg == 0 ? 2 : stg - 1;  // (lc + 2) % 3: the stage of chunk lc - 1
-            if (more) wait_vm<WMIN>();       // this chunk's halo and weight tiles have landed (chunk lc + 1's weights may fly) ...
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();    // ... for every wave; every wave has left the previous chunk
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                hrow[i] = hp_base[i];
-                asm volatile("" : "+v"(hrow[i]));
-            }
-            const char* wchunk = w_smem + stg * WSTAGE;
-            // operand fragments one k-step ahead in two register sets: with one wave per SIMD nothing else hides the LDS
-            // latency of a read that the next MFMA waits for
-            f16x8 af[2][MI], wf[2][NI];
-            {
-                const TapAddr ta0 = tap_addr(halo_off, 0);
-                read_frags(wchunk, ta0, 0, af[0], wf[0]);
-            }
-            static_for<0, 9>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
-                const char* wst = wchunk + t * WTILE;
-                static_for<0, 4>([&](auto kt) {
-                    constexpr int ks = decltype(kt)::value;
-                    constexpr int slot = t * 4 + ks;      // request slot of this k-step
-                    if constexpr (ks < 3) {
-                        read_frags(wst, ta, ks + 1, af[(slot + 1) & 1], wf[(slot + 1) & 1]);
-                    } else if constexpr (t < 8) {
-                        const TapAddr tn_ = tap_addr(halo_off, tapoff_of(t + 1));
-                        read_frags(wst + WTILE, tn_, 0, af[(slot + 1) & 1], wf[(slot + 1) & 1]);
-                    }
-                    mma(af[slot & 1], wf[slot & 1]);
-                    if constexpr (slot < MAXHP) {
-                        if (more) issue_halo(std::integral_constant<int, slot>{}, csn, nxt_halo);
-                    } else if constexpr (slot < NREQ) {
-                        constexpr int wq = slot - MAXHP;
-                        if (more2) issue_w_piece(std::integral_constant<int, wq % WPW>{}, c + 2, wq / WPW, stg2);
-                    }
-                });
-            });
-            stg = stg == 2 ? 0 : stg + 1;
-        }
-    } else if constexpr (MODE == 0) {
-        // ---- one barrier at the top of every tap
-        for (int lc = 0; lc < ncl; ++lc) {
-            const int c = c_begin + lc;
-            const int halo_off = (lc & 1) * p.halo_bytes;
-            const unsigned nxt_halo = lds0 + (unsigned)(((lc & 1) ^ 1) * p.halo_bytes);
-            const bool more = lc + 1 < ncl;
-            const ChunkSrc csn = chunk_src(more ? c + 1 : c);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                hrow[i] = hp_base[i];
-                asm volatile("" : "+v"(hrow[i]));
-            }
-            static_for<0, 9>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                const int stage = (lc & 1) ^ (t & 1);
-                wait_vm<0>();                    // this tap's weight tile (and every older piece) has landed ...
-                __builtin_amdgcn_s_barrier();    // ... for every wave; every wave is done with the previous tap
-                asm volatile("" ::: "memory");
-                if constexpr (t < 8) issue_w(c, t + 1, stage ^ 1);
-                else if (more) issue_w(c + 1, 0, stage ^ 1);
-                if constexpr (t < 8) {
-                    if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
-                }
-                const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
-                const char* wst = w_smem + stage * WSTAGE;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    f16x8 af[MI], wf[NI];
-                    read_frags(wst, ta, ks, af, wf);
-                    mma(af, wf);
-                }
-            });
-        }
-    } else {
+    {
         // ---- barrier in the middle of a tap, fragments one k-step ahead (sets F0 / F1), weight tiles two taps ahead
         f16x8 a0f[MI], w0f[NI], a1f[MI], w1f[NI];
         wait_vm<0>();
@@ -412,7 +298,7 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                 constexpr int stage = t % 3;   // (9 lc + t) % 3
                 const char* wst = w_smem + stage * WSTAGE;
                 const TapAddr ta = tap_addr(halo_off, tapoff_of(t));
-                auto pin = [&]() { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); };
+                auto pin = [&]() { __builtin_amdgcn_sched_barrier(0); };
                 read_frags(wst, ta, 1, a1f, w1f);
                 pin();
                 mma(a0f, w0f);
@@ -425,40 +311,15 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
                 wait_vm<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr (!SPREAD) {
-                    if constexpr (t + 2 < 9) issue_w(c, t + 2, (t + 2) % 3);
-                    else if (more) issue_w(c + 1, t + 2 - 9, (t + 2) % 3);
-                    if constexpr (t < 8) {
-                        if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
-                    }
-                    read_frags(wst, ta, 3, a1f, w1f);
-                    pin();
-                    mma(a0f, w0f);
-                    pin();
-                } else {
-                    // fragment requests first, then one LDS-DMA piece behind each of the first MFMAs: the matrix pipe runs
-                    // while the request is issued, instead of idling through a burst of WPW + HPT pieces
-                    read_frags(wst, ta, 3, a1f, w1f);
-                    pin();
-                    constexpr int NPIECE = WPW + HPT;
-                    static_for<0, MI * NI>([&](auto mt) {
-                        constexpr int m = decltype(mt)::value;
-                        acc[m / NI][m % NI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0f[m % NI], a0f[m / NI], acc[m / NI][m % NI], 0, 0, 0);
-                        pin();
-                        static_for<0, NPIECE>([&](auto pt) {
-                            constexpr int pc = decltype(pt)::value;
-                            if constexpr (pc * (MI * NI) / NPIECE == m) {   // spread over the MFMAs of this k-step
-                                if constexpr (pc < WPW) {
-                                    if constexpr (t + 2 < 9) issue_w_piece(std::integral_constant<int, pc>{}, c, t + 2, (t + 2) % 3);
-                                    else if (more) issue_w_piece(std::integral_constant<int, pc>{}, c + 1, t + 2 - 9, (t + 2) % 3);
-                                } else if constexpr (t < 8) {
-                                    if (more) issue_halo(std::integral_constant<int, t * HPT + pc - WPW>{}, csn, nxt_halo);
-                                }
-                                pin();
-                            }
-                        });
-                    });
+                if constexpr (t + 2 < 9) issue_w(c, t + 2, (t + 2) % 3);
+                else if (more) issue_w(c + 1, t + 2 - 9, (t + 2) % 3);
+                if constexpr (t < 8) {
+                    if (more) static_for<t * HPT, (t + 1) * HPT>([&](auto jt) { issue_halo(jt, csn, nxt_halo); });
                 }
+                read_frags(wst, ta, 3, a1f, w1f);
+                pin();
+                mma(a0f, w0f);
+                pin();
                 if constexpr (t < 8) {
                     const TapAddr tn_ = tap_addr(halo_off, tapoff_of(t + 1));
                     read_frags(w_smem + ((t + 1) % 3) * WSTAGE, tn_, 0, a0f, w0f);
@@ -545,108 +406,8 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
         return ((img0 + grp) * p.Hv + y0 + (r >> p.ltw)) * p.Wv + x0 + (r & (p.tw - 1));
     };
 
-    // ---- split-K with tickets (d.sync: two zeroed counters per tile, re-armed here): the blocks of a tile draw a ticket when
-    // their chunks are done.  Tickets 0 .. nsplit - 2 leave their fp32 accumulators in the workspace in REGISTER order
-    // ([8-byte group][thread]: coalesced, no index arithmetic) and bump the tile's `done` counter; the block with the LAST
-    // ticket keeps its accumulators in registers, waits until the others have published (they hold tickets, so they are
-    // running: the wait cannot deadlock), adds their slabs in ticket order and carries on into the fused epilogue.  One
-    // slab less is written and read than with the reduce kernel, no second launch, no fp32 round trip of the last partial.
-    // Coherence (XCD L2s are not coherent): slab stores and loads are agent-scope relaxed atomics (sc1: write-through /
-    // L1 bypass), ordered against the counters by s_waitcnt vmcnt(0) + the workgroup barrier (MI355X guide, R1 form).
-    if (gridDim.y > 1 && d.sync != nullptr) {
-        // an atomic add that returns the old value, executed in the XCD's L2 (sc0 = return; no sc1: not device scope).  Inline
-        // asm on purpose: the compiler may turn a workgroup-scope `fetch_add(p, 0)` into a plain load, which the CU's L1 would
-        // then serve for ever
-        auto l2_add = [](int* ptr, int v) {
-            int old;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(ptr), "v"(v) : "memory");
-            return old;
-        };
-        typedef unsigned long long u64;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        constexpr int G2 = MI * NI * 8;   // 8-byte groups per thread
-        const int nsplit = gridDim.y;
-        const int tile_id = tm * p.g.tiles_n + tn;
-        int* ticket_ctr = d.sync + 2 * tile_id;
-        int* done_ctr = ticket_ctr + 1;
-        int* flag = reinterpret_cast<int*>(smem);
-        // p.g.xcd_local (round 4): the launcher has checked that the blocks of a tile share an XCD (block b runs on XCD b % 8 and
-        // the tile count is a multiple of 8, so blockIdx.x decides the XCD for every split).  That XCD's L2 is then the coherence
-        // point of everything the tile's blocks exchange: slabs travel as PLAIN stores / loads (a store is in L2 once vmcnt has
-        // drained; the last block's loads are first touches of those lines in this launch, and L1 is invalidated between
-        // launches), the counters as workgroup-scope atomics (every atomic executes in L2) -- no write-through, no trip to the
-        // device-coherent memory side, which is what made the agent-scope form below lose to the reduce launch.
-        const bool local = p.g.xcd_local != 0;
-        if (tid == 0)
-            *flag = local ? l2_add(ticket_ctr, 1) : __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = *flag;
-        u64* slab0 = reinterpret_cast<u64*>(d.ws) + (size_t)tile_id * (nsplit - 1) * (size_t)(G2 * NT);
-        if (ticket < nsplit - 1) {
-            u64* mine = slab0 + (size_t)ticket * (G2 * NT) + tid;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        const u64 v = __builtin_bit_cast(u64, f32x2{acc[i][j][g * 2], acc[i][j][g * 2 + 1]});
-                        if (local) mine[((i * NI + j) * 8 + g) * NT] = v;
-                        else __hip_atomic_store(mine + ((i * NI + j) * 8 + g) * NT, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are acknowledged (L2 / device scope)
-            __syncthreads();                                   // ... and every wave's
-            if (tid == 0) {
-                if (local) l2_add(done_ctr, 1);
-                else __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        if (tid == 0) {
-            unsigned spins = 0;
-            for (;;) {
-                const int done = local ? l2_add(done_ctr, 0)   // an RMW: never served by L1
-                                       : __hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (done >= nsplit - 1) break;
-                __builtin_amdgcn_s_sleep(8);
-                // never seen (ticket holders are resident).  A bounded wait cannot hang the device, and giving up must not
-                // look like success: trap -- the launch fails, the host sees the error, the counters are NOT re-armed
-                if (++spins > (1u << 24)) __builtin_trap();
-            }
-            if (local) {   // re-arm for the next launch
-                l2_add(ticket_ctr, -nsplit);
-                l2_add(done_ctr, -(nsplit - 1));
-            } else {
-                __hip_atomic_store(ticket_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(done_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        asm volatile("" ::: "memory");
-        const u64* src = slab0 + tid;
-        for (int s = 0; s < nsplit - 1; ++s, src += G2 * NT) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    u64 v[8];
-#pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        v[g] = local ? src[((i * NI + j) * 8 + g) * NT]
-                                     : __hip_atomic_load(src + ((i * NI + j) * 8 + g) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        const f32x2 f = __builtin_bit_cast(f32x2, v[g]);
-                        acc[i][j][g * 2] += f.x;
-                        acc[i][j][g * 2 + 1] += f.y;
-                    }
-                }
-        }
-        __syncthreads();   // the ticket word in LDS has been read by everyone: the epilogue tile may overwrite it
-    }
-
-    // ---- split-K without counters: fp32 slabs for splitk_reduce_kernel, straight from registers
-    if (gridDim.y > 1 && d.sync == nullptr) {
+    // ---- split over channel chunks: fp32 slabs for splitk_reduce_kernel, straight from registers
+    if (gridDim.y > 1) {
         float* base = d.ws + (size_t)split * (size_t)d.M * d.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -819,9 +580,9 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_halo_kernel(const ConvHa
 
 template <int BM, int BN, int WM, int WN, int NT, int MODE, bool SKIP = false>
 int launch_conv_halo(const ConvHaloArgs& a, int nsplit, hipStream_t stream) {
-    constexpr int WST = MODE == 0 ? 2 : 3;
+    constexpr int WST = 3;
     constexpr int EPI = stat_lds_bytes(BM, BN);   // epilogue tile + the lane scratch of the statistics pass
-    const int main_bytes = 2 * a.halo_bytes + WST * (MODE == 4 ? 9 : 1) * BN * 128;
+    const int main_bytes = 2 * a.halo_bytes + WST * BN * 128;
     const int lds = main_bytes > EPI ? main_bytes : EPI;
     if (lds > 160 * 1024) {
         vd_set_error("conv3x3_halo: %d bytes of LDS", lds);

@@ -3,7 +3,6 @@
 // weight fragments in flight, the pixel fragments and the addresses.
 #include "conv_wstream_kernel.h"
 #include "conv_wsk_kernel.h"
-#include "conv_wreg_kernel.h"
 #include "gemm_wstream_kernel.h"
 
 // gemm.hip
@@ -44,14 +43,10 @@ int launch_wstream(const WsArgs& w, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL((conv3x3_wstream_kernel<D, OCC, IPB>), dim3(blocks), dim3(256), LDS, stream, w);
     return vd_check_launch("vd_conv3x3_wstream_f16");
 }
-// images per block of the split kernel: 2; opt-in (VD_WSTREAM_IPB=4) 4 -- a wave owns 32 channels over 256 pixels, every weight
-// byte enters half as many CUs.  Built to test whether the launch is bound by what a CU ingests: it is not -- 33.7 vs 32.0 us
-// per launch in isolation, 10.44 / 10.47 vs 10.41 ms per forward (profiles/HISTORY.md, round 5): correct, not faster.
-int wstream_ipb(const VdGemmDesc& d) {
-    const char* env = getenv("VD_WSTREAM_IPB");
-    if (!(env && env[0] == '4')) return 2;
-    return ((d.M / 64) % 4 == 0 && d.N % 128 == 0) ? 4 : 2;
-}
+// images per block of the split kernel: 2.  (Round 5 also built a 4-images-per-block geometry -- a wave owns 32 channels over 256
+// pixels, every weight byte enters half as many CUs -- to test whether the launch is bound by what a CU ingests: it is not, 33.7 vs
+// 32.0 us per launch in isolation, 10.44 / 10.47 vs 10.41 ms per forward (profiles/HISTORY.md); removed in round 6.)
+constexpr int wstream_ipb(const VdGemmDesc&) { return 2; }
 }  // namespace
 
 // Development hook (tests, A/B runs): instance 0 = 12 k-steps of weights in flight at one wave per SIMD (default), 1 = 9 at
@@ -82,7 +77,7 @@ bool wsk_takes(const VdGemmDesc& d, int nchunks, int nskip) {
     const char* min_env = getenv("VD_WSK_MIN_BLOCKS");
     const int min_blocks = min_env ? atoi(min_env) : 128;
     if (d.split_k > 1) return false;   // an explicit split factor asks for the split kernel
-    if (nskip > 0 || (d.flags & VD_EPI_GROUPNORM) || nchunks < 4 || nchunks > WK_MAXC) return false;
+    if (nskip > 0 || nchunks < 4 || nchunks > WK_MAXC) return false;
     if ((d.ldc & 7) || ((d.flags & VD_EPI_RESIDUAL) && (d.ldr & 7))) return false;
     if ((d.flags & VD_EPI_RESIDUAL) && (d.flags & VD_EPI_ROWVEC) && d.act != VD_ACT_NONE) return false;
     return (d.M / 128) * (d.N / 32) >= min_blocks;
@@ -90,11 +85,9 @@ bool wsk_takes(const VdGemmDesc& d, int nchunks, int nskip) {
 // split factor of the split kernel for `tiles` output tiles and `nchunks` chunks (the launcher's rule)
 int wstream_split(const VdGemmDesc& d, int tiles, int nchunks, int* cps_out) {
     int var = g_ws_variant.load(std::memory_order_relaxed), target = g_ws_blocks.load(std::memory_order_relaxed);
-    if (var < 0) {   // development switches (VD_WSTREAM_VAR / VD_WSTREAM_BLOCKS or vd_conv3x3_wstream_set_variant), read once
-        const char* var_env = getenv("VD_WSTREAM_VAR");
-        const char* tgt_env = getenv("VD_WSTREAM_BLOCKS");
-        var = var_env ? atoi(var_env) : 0;
-        target = tgt_env ? atoi(tgt_env) : 256;
+    if (var < 0) {   // defaults (vd_conv3x3_wstream_set_variant changes them: development hook)
+        var = 0;
+        target = 256;
         g_ws_variant.store(var, std::memory_order_relaxed);
         g_ws_blocks.store(target, std::memory_order_relaxed);
     }
@@ -182,8 +175,7 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
         k.w.skip_cps = 0;
         k.g = a;
         {
-            const char* rot_env = getenv("VD_WSK_ROTATE");   // development switch
-            k.rotate = rot_env ? atoi(rot_env) : 1;
+            k.rotate = 1;
         }
         static std::atomic<unsigned long long> done{0};
         int dev = 0;
@@ -208,19 +200,11 @@ extern "C" int vd_conv3x3_wstream_f16(const VdGemmDesc* dp, const void* w_stream
     w.nsplit = nsplit;
     w.skip_cps = (w.nskip + nsplit - 1) / nsplit;
     int lrc;
-    if (ipb == 4) {
-        switch (var) {
-            case 1: lrc = launch_wstream<9, 1, 4>(w, tiles * nsplit, stream); break;
-            case 2: lrc = launch_wstream<12, 1, 4>(w, tiles * nsplit, stream); break;
-            default: lrc = launch_wstream<18, 1, 4>(w, tiles * nsplit, stream); break;
-        }
-    } else {
-        switch (var) {
-            case 1: lrc = launch_wstream<9, 1>(w, tiles * nsplit, stream); break;
-            case 2: lrc = launch_wstream<4, 2>(w, tiles * nsplit, stream); break;
-            case 3: lrc = launch_wstream<6, 2>(w, tiles * nsplit, stream); break;
-            default: lrc = launch_wstream<12, 1>(w, tiles * nsplit, stream); break;
-        }
+    switch (var) {
+        case 1: lrc = launch_wstream<9, 1>(w, tiles * nsplit, stream); break;
+        case 2: lrc = launch_wstream<4, 2>(w, tiles * nsplit, stream); break;
+        case 3: lrc = launch_wstream<6, 2>(w, tiles * nsplit, stream); break;
+        default: lrc = launch_wstream<12, 1>(w, tiles * nsplit, stream); break;
     }
     if (lrc != VD_OK) return lrc;
     return vd_gemm_launch_reduce(&a, nsplit, stream);
@@ -247,8 +231,7 @@ extern "C" int vd_gemm_wstream_supported(const VdGemmDesc* dp) {
 
 namespace {
 int gw_split(const VdGemmDesc& d, int tiles, int nchunks) {
-    static const char* tgt_env = getenv("VD_GEMM_WSTREAM_BLOCKS");
-    const int target = tgt_env ? atoi(tgt_env) : 256;
+    const int target = 256;
     int nsplit = d.split_k > 0 ? d.split_k : (target + tiles / 2) / tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nchunks) nsplit = nchunks;
@@ -305,174 +288,4 @@ extern "C" int vd_gemm_wstream_f16(const VdGemmDesc* dp, const void* w_stream, h
     const int lrc = vd_check_launch("vd_gemm_wstream_f16");
     if (lrc != VD_OK) return lrc;
     return vd_gemm_launch_reduce(&a, nsplit, stream);
-}
-
-
-// ---- weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h) -------------------------------------
-namespace {
-std::atomic<int> g_wreg_blocks{-1};
-
-// geometry + launch plan; nullptr on success, else why the kernel does not take the problem
-const char* wreg_plan(const GemmArgs& a, WrArgs& w) {
-    const VdGemmDesc& d = a.d;
-    if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.batch != 1) return "3x3 / stride 1 / pad 1, batch 1";
-    if ((d.flags & (VD_EPI_LNFOLD | VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M)) || d.act == VD_ACT_GEGLU) return "a plain fp16 epilogue";
-    if (d.c0 % 64 != 0 || d.c1 % 64 != 0 || d.N % 8 != 0) return "channel counts in multiples of 64";
-    const int Hv = d.Hin << d.ups, Wv = d.Win << d.ups;
-    if (d.Hout != Hv || d.Wout != Wv) return "symmetric zero padding";
-    const long npix = (long)Hv * Wv;
-    if (d.M % npix != 0) return "whole images";
-    const int tw = (Wv % 32 == 0) ? 32 : (Wv % 16 == 0 ? 16 : 0);
-    if (tw == 0 || Hv % (128 / tw) != 0) return "an output grid that tiles into 4 x 32 or 8 x 16 pixel patches";
-    if ((d.M / npix) * d.Hin * d.Win >= (1l << 28)) return "fewer input pixels";
-    if ((d.ldc & 7) || ((d.flags & VD_EPI_RESIDUAL) && (d.ldr & 7))) return "16-byte aligned output rows";
-    // column tiles: widths 512 / 384 / 320 / 256 / 128 = wave layouts (4,4) (3,3) (3,2) (2,2) (1,1); the fewest tiles that sum
-    // to N exactly (small dynamic program over multiples of 64), widest first
-    static const int widths[5] = {512, 384, 320, 256, 128};
-    static const int lay0[5] = {4, 3, 3, 2, 1}, lay1[5] = {4, 3, 2, 2, 1};
-    if (d.N % 64 != 0 || d.N / 64 > 64) return "an output width that is a multiple of 64 (at most 4096)";
-    int best[65], pick[65];   // best[u]: fewest tiles covering u * 64 channels (0 = impossible), pick[u]: the first tile of it
-    best[0] = 0;
-    for (int u = 1; u <= d.N / 64; ++u) {
-        best[u] = 1 << 20;
-        pick[u] = -1;
-        for (int k = 0; k < 5; ++k) {
-            const int wu = widths[k] / 64;
-            if (wu <= u && best[u - wu] + 1 < best[u]) {
-                best[u] = best[u - wu] + 1;
-                pick[u] = k;
-            }
-        }
-    }
-    if (best[d.N / 64] > WR_MAX_TN) return "an output width that splits into column tiles of 512 / 384 / 320 / 256 / 128";
-    int ntn = 0, n0 = 0;
-    for (int u = d.N / 64; u > 0; u -= widths[pick[u]] / 64) {
-        w.tn_n0[ntn] = n0;
-        w.tn_ni0[ntn] = lay0[pick[u]];
-        w.tn_ni1[ntn] = lay1[pick[u]];
-        n0 += widths[pick[u]];
-        ++ntn;
-    }
-    w.ntn = ntn;
-    w.g = a;
-    w.tw = tw;
-    w.ltw = tw == 32 ? 5 : 4;
-    w.rows = 128 / tw;
-    w.pitch = tw + 2;
-    w.hpx = (w.rows + 2) * w.pitch;
-    w.mg_pitch = (1 << 20) / w.pitch + 1;
-    w.tiles_x = Wv / tw;
-    w.tiles_y = Hv / w.rows;
-    w.Hv = Hv;
-    w.Wv = Wv;
-    w.nchunks = (d.c0 + d.c1) / 64;
-    w.tiles_m = (int)(d.M / 128);
-    w.halo_bytes = ((w.hpx + 7) / 8) * 1024;
-    // split over chunks until about one block per CU (one wave per SIMD: one block per CU is resident)
-    int target = g_wreg_blocks.load(std::memory_order_relaxed);
-    if (target < 0) {
-        const char* e = getenv("VD_WREG_BLOCKS");
-        target = e ? atoi(e) : 256;
-        g_wreg_blocks.store(target, std::memory_order_relaxed);
-    }
-    const long tiles = (long)w.tiles_m * ntn;
-    int nsplit = d.split_k > 0 ? d.split_k : (int)((target + tiles / 2) / tiles);
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 1 && d.ws == nullptr) nsplit = 1;
-    if (nsplit > w.nchunks) nsplit = w.nchunks;
-    if (nsplit > VD_MAX_SPLIT_K) nsplit = VD_MAX_SPLIT_K;
-    w.cps = (w.nchunks + nsplit - 1) / nsplit;
-    w.nsplit = (w.nchunks + w.cps - 1) / w.cps;
-    return nullptr;
-}
-
-int wreg_lds_bytes(const WrArgs& w) {
-    int epi = 0;
-    if (w.nsplit == 1)
-        for (int t = 0; t < w.ntn; ++t) {
-            const int bn = (w.tn_ni0[t] + w.tn_ni1[t]) * 64;
-            const int lanes = 256 / (bn / 8) < 8 ? 256 / (bn / 8) : 8;
-            const int b = 128 * (bn + 8) * 2 + lanes * bn * 8;
-            if (b > epi) epi = b;
-        }
-    const int main_bytes = 2 * w.halo_bytes;
-    return main_bytes > epi ? main_bytes : epi;
-}
-
-int wreg_prepare(const VdGemmDesc* dp, const void* w_stream, GemmArgs& a, WrArgs& w, const char** why) {
-    VdGemmDesc tmp = *dp;
-    tmp.w = w_stream ? w_stream : dp->w;
-    tmp.out_stats = nullptr;
-    const int rc = vd_gemm_normalise(&tmp, &a);
-    if (rc != VD_OK) return rc;
-    a.d.sync = nullptr;
-    *why = wreg_plan(a, w);
-    return VD_OK;
-}
-}  // namespace
-
-extern "C" int vd_conv3x3_wreg_set_blocks(int target_blocks) {
-    VD_REQUIRE(target_blocks > 0, "vd_conv3x3_wreg_set_blocks: bad argument");
-    g_wreg_blocks.store(target_blocks, std::memory_order_relaxed);
-    return VD_OK;
-}
-
-// rows per out_stats partial of the launch planned for desc (128: the kernel's own epilogue, one partial per patch; 64: split
-// over chunks, the reduce kernel); 0 with *supported = 0 when the geometry does not fit
-extern "C" int vd_conv3x3_wreg_plan(const VdGemmDesc* dp, int* supported, int* nsplit, int* stat_rows) {
-    VD_REQUIRE(dp != nullptr, "vd_conv3x3_wreg_plan: null descriptor");
-    GemmArgs a;
-    WrArgs w;
-    const char* why = nullptr;
-    const int rc = wreg_prepare(dp, dp->w, a, w, &why);
-    if (rc != VD_OK) return rc;
-    if (supported) *supported = why == nullptr ? 1 : 0;
-    if (nsplit) *nsplit = why == nullptr ? w.nsplit : 0;
-    if (stat_rows) {
-        const VdGemmDesc& d = a.d;
-        const int HW = d.stat_img_rows;
-        const bool ok = why == nullptr && HW == w.Hv * w.Wv && HW % 128 == 0;
-        *stat_rows = !ok ? 0 : (w.nsplit == 1 ? 128 : 64);
-    }
-    return VD_OK;
-}
-
-extern "C" int vd_conv3x3_wreg_f16(const VdGemmDesc* dp, const void* w_stream, hipStream_t stream) {
-    VD_REQUIRE(dp != nullptr && w_stream != nullptr, "vd_conv3x3_wreg_f16: null argument");
-    VD_REQUIRE(dp->stat_sums == nullptr, "vd_conv3x3_wreg_f16: stat_sums is taken by vd_gemm_f16 / vd_ff_chain_f16 only");
-    VD_REQUIRE(((size_t)w_stream & 15) == 0, "vd_conv3x3_wreg_f16: w_stream must be 16-byte aligned");
-    GemmArgs a;
-    WrArgs w;
-    const char* why = nullptr;
-    const int rc = wreg_prepare(dp, w_stream, a, w, &why);
-    if (rc != VD_OK) return rc;
-    VD_REQUIRE(why == nullptr, "vd_conv3x3_wreg_f16 takes %s", why ? why : "");
-    VdGemmDesc& d = w.g.d;
-    d.out_stats = dp->out_stats;
-    a.d.out_stats = dp->out_stats;
-    if (d.out_stats != nullptr) {
-        VD_REQUIRE(d.stat_img_rows == w.Hv * w.Wv && ((size_t)d.out_stats & 7) == 0, "vd_conv3x3_wreg_f16: out_stats describe whole images");
-        w.g.stat_rows = a.stat_rows = w.nsplit == 1 ? 128 : 64;
-    }
-    static const char* nt_env = getenv("VD_GEMM_NT");
-    w.g.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-    w.wp = reinterpret_cast<const uint4*>(w_stream);
-    const int lds = wreg_lds_bytes(w);
-    VD_REQUIRE(lds <= 160 * 1024, "vd_conv3x3_wreg_f16: %d bytes of LDS", lds);
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wreg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            vd_set_error("vd_conv3x3_wreg_f16: cannot reserve LDS: %s", hipGetErrorString(e));
-            return VD_ERR_LAUNCH;
-        }
-        done.fetch_or(bit, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(conv3x3_wreg_kernel, dim3(w.tiles_m * w.ntn * w.nsplit), dim3(256), lds, stream, w);
-    const int lrc = vd_check_launch("vd_conv3x3_wreg_f16");
-    if (lrc != VD_OK || w.nsplit == 1) return lrc;
-    return vd_gemm_launch_reduce(&a, w.nsplit, stream);
 }

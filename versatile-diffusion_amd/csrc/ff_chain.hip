@@ -474,8 +474,7 @@ extern "C" int vd_ff_chain_f16(const VdFfChain* c, hipStream_t stream) {
     a.wp = (const f16*)c->wp; a.bp = (const f16*)c->bp; a.r = (const f16*)c->res; a.y = (f16*)c->out; a.out_stats = c->out_stats;
     a.stat_sums = reinterpret_cast<unsigned long long*>(c->stat_sums); a.img_rows = (int)c->stat_img_rows;
     a.M = (int)c->M; a.eps = c->ln_eps; a.alpha = c->alpha;
-    static const char* nt_env = getenv("VD_GEMM_NT");
-    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    a.nt_store = 1;   // non-temporal stores of write-once outputs
     if (pre && post) return launch_ffc<true, true>(a, stream);
     if (pre) return launch_ffc<true, false>(a, stream);
     return launch_ffc<false, true>(a, stream);

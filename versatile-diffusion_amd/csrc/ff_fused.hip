@@ -397,9 +397,7 @@ extern "C" int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void*
     FFArgs a;
     a.x = (const f16*)x; a.w1 = (const f16*)w1_packed; a.b1 = (const f16*)b1_packed; a.w2 = (const f16*)w2; a.b2 = (const f16*)b2;
     a.res = (const f16*)res; a.y = (f16*)y; a.M = (int)M; a.eps = ln_eps;
-    static const char* nt_env = getenv("VD_GEMM_NT");
-    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-    static const char* ver_env = getenv("VD_FF_VER");   // development switch: 0 = epilogue in front of stage 2
+    a.nt_store = 1;   // non-temporal stores of write-once outputs
     const dim3 grid((unsigned)((M + FF_BM - 1) / FF_BM));
 #ifdef VD_FF_ABLATIONS
     static const char* abl_env = getenv("VD_FF_ABL");
@@ -410,7 +408,6 @@ extern "C" int vd_ff_geglu_f16(const void* x, const void* w1_packed, const void*
     if (abl == 4) { hipLaunchKernelGGL((ff_geglu_kernel<0, 4>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
     if (abl == 5) { hipLaunchKernelGGL((ff_geglu_kernel<0, 5>), grid, dim3(512), FF_LDS, stream, a); return vd_check_launch("ff abl"); }
 #endif
-    if (ver_env && ver_env[0] == '0') hipLaunchKernelGGL(ff_geglu_kernel<0>, grid, dim3(512), FF_LDS, stream, a);
-    else hipLaunchKernelGGL(ff_geglu_kernel<1>, grid, dim3(512), FF_LDS, stream, a);
+    hipLaunchKernelGGL(ff_geglu_kernel<1>, grid, dim3(512), FF_LDS, stream, a);
     return vd_check_launch("vd_ff_geglu_f16");
 }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
 // The same reduction for outputs that feed a GroupNorm (VdGemmDesc.out_stats): a block owns 64 rows x (8 OCT) columns, sums the
 // slabs, runs the fused epilogue and emits per-channel (mean, M2) of the 64 values it stored per channel (csrc/gn_fused.hip).
 // grid (ceil(N / (8 OCT)), M / 64), 256 threads = OCT column octets x 256 / OCT row lanes, RPT = 64 OCT / 256 rows per thread.
-// OCT = 8 (default); OCT = 16 (512-byte row pieces, 16 loads in flight per slab pair) is an opt-in that measured slower.
+// OCT = 8 (OCT = 16 -- 512-byte row pieces, 16 loads in flight per slab pair -- measured slower).
 template <int OCT>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs p, int nsplit) {
     constexpr int LANES = 256 / OCT, RPT = 64 / LANES, COLS = OCT * 8;
@@ -194,201 +194,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const GemmArgs
 
 inline void launch_reduce_stats(const GemmArgs& a, int nsplit, hipStream_t stream) {
     const VdGemmDesc& d = a.d;
-    // 128-column blocks (512-byte row pieces, twice the loads in flight) measured SLOWER than 64-column blocks inside the
-    // forward (10.98 vs 10.89 ms: half as many blocks): development switch VD_REDUCE_WIDE=1 only
-    static const char* w_env = getenv("VD_REDUCE_WIDE");
-    const bool wide = (w_env && w_env[0] == '1') && (long)((d.N + 127) / 128) * (d.M / 64) >= 256;
-    if (wide) hipLaunchKernelGGL(splitk_reduce_stats_kernel<16>, dim3((d.N + 127) / 128, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
-    else hipLaunchKernelGGL(splitk_reduce_stats_kernel<8>, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
+    // (128-column blocks -- 512-byte row pieces, twice the loads in flight -- measured SLOWER inside the forward, 10.98 vs 10.89 ms:
+    // half as many blocks)
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel<8>, dim3((d.N + 63) / 64, d.M / 64, 1), dim3(256), 0, stream, a, nsplit);
 }
 
-// Split-K reduction fused with the GroupNorm (+ SiLU) that CONSUMES the result (VD_EPI_GROUPNORM): the conv1 -> GroupNorm ->
-// SiLU half of a ResBlock whose conv ran split over K.  A block owns one sample and a slab of whole groups: it sums the
-// nsplit fp32 slabs of its [HW x slab] panel into REGISTERS (+ bias + per-image row vector, activation, alpha), computes the
-// exact two-pass statistics of its groups there (mean, then sum (x - mean)^2: the panel holds every value of the groups),
-// and stores the normalised fp16 panel -- the raw conv output, its statistics buffer, the table launch and the apply launch
-// (reduce 12.5 us + 4.85 + 6-10 us) do not exist.  grid (N / slab, B), NT = blockDim.x threads = slab / 4 column quads x row
-// lanes, RN_ITER rows per thread at most (v[] + the loads of one slab in flight fit the 128 registers of a 1024-thread block).
-constexpr int RN_ITER = 12;
-struct RnArgs {
-    GemmArgs g;
-    int nsplit, HW, slab, cg;   // rows per sample, channels per block (whole groups, multiple of 4), channels per group
-};
-
-__global__ __launch_bounds__(1024) void splitk_reduce_groupnorm_kernel(const RnArgs p) {
-    extern __shared__ float rn_lds[];   // [RL][slab] partial sums, then [slab] channel sums, [ng] group values
-    const VdGemmDesc& d = p.g.d;
-    const EpiCtx e = make_epi(d, 0);
-    const int NT = blockDim.x, tid = threadIdx.x;
-    const int SQ = p.slab / 4, RL = NT / SQ;
-    const int cq = tid % SQ, rl = tid / SQ;
-    const bool active = rl < RL;
-    const int b = blockIdx.y, n0 = blockIdx.x * p.slab;
-    const int col = n0 + cq * 4;
-    const size_t slab_elems = (size_t)d.M * d.N;
-    float4 v[RN_ITER];
-    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) {
-        if (e.flags & VD_EPI_BIAS) {
-            U2H4 t;
-            t.u = *reinterpret_cast<const uint2*>(e.bias + col);
-            add = make_float4((float)t.e[0], (float)t.e[1], (float)t.e[2], (float)t.e[3]);
-        }
-        if (e.flags & VD_EPI_ROWVEC) {   // rows_per_batch == HW (checked by the planner): one row vector per sample
-            U2H4 t;
-            t.u = *reinterpret_cast<const uint2*>(e.rowvec + (size_t)b * e.N + col);
-            add.x += (float)t.e[0]; add.y += (float)t.e[1]; add.z += (float)t.e[2]; add.w += (float)t.e[3];
-        }
-    }
-    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int it = 0; it < RN_ITER; ++it) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // slab by slab, ALL rows of the thread requested before any is added: RN_ITER independent 16-byte loads in flight (a
-    // per-row loop over the slabs left one load in flight per thread and ran three times slower than the plain reduce)
-    const float* wbase = d.ws + ((size_t)b * p.HW + rl) * d.N + col;
-    const size_t row_step = (size_t)RL * d.N;
-    for (int s = 0; s < p.nsplit; ++s) {
-        float4 x[RN_ITER];
-        const float* ws_ = wbase + (size_t)s * slab_elems;
-#pragma unroll
-        for (int it = 0; it < RN_ITER; ++it) {
-            const bool ok = active && rl + it * RL < p.HW;
-            x[it] = ok ? *reinterpret_cast<const float4*>(ws_ + (size_t)it * row_step) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int it = 0; it < RN_ITER; ++it) {
-            v[it].x += x[it].x; v[it].y += x[it].y; v[it].z += x[it].z; v[it].w += x[it].w;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < RN_ITER; ++it) {
-        if (active && rl + it * RL < p.HW) {
-            float4 a = v[it];
-            a.x = apply_act(e.act, a.x + add.x) * e.alpha;
-            a.y = apply_act(e.act, a.y + add.y) * e.alpha;
-            a.z = apply_act(e.act, a.z + add.z) * e.alpha;
-            a.w = apply_act(e.act, a.w + add.w) * e.alpha;
-            v[it] = a;
-            psum.x += a.x; psum.y += a.y; psum.z += a.z; psum.w += a.w;
-        }
-    }
-    // ---- group statistics, two passes over the registers; block reduction: row lanes -> channels -> groups (fixed order)
-    const int ng = p.slab / p.cg;
-    float* red = rn_lds;                       // [RL][slab]
-    float* chs = rn_lds + RL * p.slab;         // [slab]
-    float* grp = chs + p.slab;                 // [2 * ng]: mean, rstd
-    const float ntot = (float)p.HW * (float)p.cg;
-    auto block_groups = [&](const float4& part, int which) {
-        if (active) *reinterpret_cast<float4*>(red + rl * p.slab + cq * 4) = part;
-        __syncthreads();
-        if (tid < p.slab) {
-            float t = 0.f;
-            for (int l = 0; l < RL; ++l) t += red[l * p.slab + tid];
-            chs[tid] = t;
-        }
-        __syncthreads();
-        if (tid < ng) {
-            float t = 0.f;
-            for (int c = 0; c < p.cg; ++c) t += chs[tid * p.cg + c];
-            grp[which * ng + tid] = which == 0 ? t / ntot : rsqrtf(t / ntot + d.gn_eps);
-        }
-        __syncthreads();
-    };
-    block_groups(psum, 0);
-    float mean[4], rstd[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mean[q] = grp[(cq * 4 + q) / p.cg];
-    float4 psq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int it = 0; it < RN_ITER; ++it) {
-        const int r = rl + it * RL;
-        if (active && r < p.HW) {
-            const float a = v[it].x - mean[0], bq = v[it].y - mean[1], c2 = v[it].z - mean[2], dq = v[it].w - mean[3];
-            psq.x += a * a; psq.y += bq * bq; psq.z += c2 * c2; psq.w += dq * dq;
-        }
-    }
-    block_groups(psq, 1);
-    if (!active) return;
-    float sc[4], sh[4];
-    {
-        U2H4 gq, bq;
-        gq.u = *reinterpret_cast<const uint2*>(reinterpret_cast<const f16*>(d.gn_gamma) + col);
-        bq.u = *reinterpret_cast<const uint2*>(reinterpret_cast<const f16*>(d.gn_beta) + col);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            rstd[q] = grp[ng + (cq * 4 + q) / p.cg];
-            sc[q] = rstd[q] * (float)gq.e[q];
-            sh[q] = (float)bq.e[q] - mean[q] * sc[q];
-        }
-    }
-    const bool silu = (d.flags & VD_EPI_GN_SILU) != 0;
-    f16* outp = reinterpret_cast<f16*>(e.out);
-#pragma unroll
-    for (int it = 0; it < RN_ITER; ++it) {
-        const int r = rl + it * RL;
-        if (r < p.HW) {
-            const float x4[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-            U2H4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float y = fmaf(x4[q], sc[q], sh[q]);
-                o.e[q] = (f16)(silu ? y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * y)) : y);
-            }
-            *reinterpret_cast<uint2*>(outp + ((size_t)b * p.HW + r) * e.ldc + col) = o.u;
-        }
-    }
-}
-
-// geometry of splitk_reduce_groupnorm_kernel for a (normalised) descriptor; false when it does not fit
-bool groupnorm_reduce_plan(const GemmArgs& a, RnArgs& r, int* threads) {
-    const VdGemmDesc& d = a.d;
-    if (!(d.flags & VD_EPI_GROUPNORM)) return false;
-    if (d.gn_gamma == nullptr || d.gn_beta == nullptr || d.gn_groups <= 0 || d.N % d.gn_groups != 0) return false;
-    if (d.batch != 1 || (d.flags & (VD_EPI_OUT_F32 | VD_EPI_LNFOLD | VD_EPI_BIAS_ALONG_M | VD_EPI_RESIDUAL)) || d.act == VD_ACT_GEGLU) return false;
-    if (d.out_stats != nullptr || d.N % 4 != 0 || d.ldc % 4 != 0) return false;
-    const int HW = d.stat_img_rows;
-    if (HW <= 0 || d.M % HW != 0 || d.M / HW > 65535) return false;
-    if ((d.flags & VD_EPI_ROWVEC) && d.rows_per_batch != HW) return false;
-    const int cg = d.N / d.gn_groups;
-    int unit = cg;   // slab unit: whole groups, whole float4 columns
-    while (unit % 4 != 0) unit += cg;
-    if (d.N % unit != 0) return false;
-    // widest slab (<= 160 channels, dividing N) whose [HW x slab] panel fits 1024 threads x RN_ITER float4
-    static const char* slab_env = getenv("VD_GN_REDUCE_SLAB");   // development switch: widest slab
-    static const int slab_max = slab_env ? atoi(slab_env) : 40;   // narrow slabs = many blocks: 256 at the 16x16 / 8x8 levels
-    int slab = 0;
-    for (int s = unit; (s <= slab_max || slab == 0) && s <= 160 && s <= d.N; s += unit)
-        if (d.N % s == 0 && (long)HW * s <= 1024l * 4 * RN_ITER) slab = s;
-    if (slab == 0) return false;
-    const int SQ = slab / 4;
-    int nt = 256;   // the fewest threads (multiples of 64 lanes, whole row-lane sets) that hold the panel
-    for (;; nt += 64) {
-        const int RL = nt / SQ;
-        if (RL > 0 && (long)RL * RN_ITER >= HW) break;
-        if (nt >= 1024) return false;
-    }
-    if ((nt / SQ) * slab * 4 + slab * 4 + 2 * (slab / cg) * 4 > 60 * 1024) return false;
-    r.g = a;
-    r.HW = HW;
-    r.slab = slab;
-    r.cg = cg;
-    *threads = nt;
-    return true;
-}
-
-int launch_reduce_groupnorm(const GemmArgs& a, int nsplit, hipStream_t stream) {
-    RnArgs r;
-    int nt = 0;
-    if (!groupnorm_reduce_plan(a, r, &nt)) {
-        vd_set_error("vd_gemm_f16: VD_EPI_GROUPNORM does not fit this launch (ask vd_gemm_groupnorm_ok first)");
-        return VD_ERR_UNSUPPORTED;
-    }
-    r.nsplit = nsplit;
-    const int RL = nt / (r.slab / 4);
-    const int lds = (RL * r.slab + r.slab + 2 * (r.slab / r.cg)) * 4;
-    hipLaunchKernelGGL(splitk_reduce_groupnorm_kernel, dim3(a.d.N / r.slab, a.d.M / r.HW, 1), dim3(nt), lds, stream, r);
-    return vd_check_launch("vd_gemm_f16/splitk_reduce_groupnorm");
-}
 
 }  // namespace
 
@@ -430,6 +240,18 @@ const CfgInfo kCfg[T_COUNT] = {
     {256, 256, "gemm_f16_kernel<256,256,64,128,512,2,64>"},
     {256, 128, "gemm_f16_kernel<256,128,64,64,512,3,64>"},   {128, 128, "gemm_f16_kernel<128,128,32,64,512,3,64>"}};
 
+// Tiles that are instantiated.  Rounds 1-5 carried 18 more as development tiles (256x128, 128x256, 128x160, the one-wave-per-SIMD
+// "b" tiles, the 32-deep / 4-stage "q" ring, 256x320, 256x256, the mid-barrier "m" loop): each lost its in-forward A/B at least
+// twice (profiles/HISTORY.md); round 6 removed the instantiations.  The table keeps their slots so configuration indices and
+// names in old profiles stay meaningful.
+bool cfg_built(int cfg) {
+    switch (cfg) {
+        case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T128x128d: case T128x64d: case T64x64d:
+            return true;
+        default: return false;
+    }
+}
+
 std::atomic<int> g_override{-1};
 
 // Tuned launch table: (M, N, K, ksize, epilogue class) -> (tile configuration, split-K), filled by the host from a file
@@ -451,7 +273,6 @@ bool cfg_emits_stats(int cfg) {
         case T128x128w8: return gemm_emits_stats<128, 128, 512, 2, 64, false>();
         case T128x64w8: return gemm_emits_stats<128, 64, 512, 2, 64, false>();
         case T128x320: return gemm_emits_stats<128, 320, 512, 2, 64, false>();
-        case T128x160: return gemm_emits_stats<128, 160, 256, 2, 64, false>();
         case T128x128d: return gemm_emits_stats<128, 128, 256, 3, 64, false>();
         case T128x64d: return gemm_emits_stats<128, 64, 256, 3, 64, false>();
         case T64x64d: return gemm_emits_stats<64, 64, 256, 3, 64, false>();
@@ -509,10 +330,7 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     VD_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "vd_gemm_f16: M=%d is not a multiple of Hout*Wout=%d", d.M, d.Hout * d.Wout);
     if (d.stat_img_rows <= 0) d.stat_img_rows = d.Hout * d.Wout;
     a.stat_rows = 0;
-    {   // development switch VD_GEMM_HOIST=0: epilogue operands are requested behind the main loop (rounds 1-3)
-        static const char* hoist_env = getenv("VD_GEMM_HOIST");
-        a.hoist = (hoist_env && hoist_env[0] == '0') ? 0 : 1;
-    }
+    a.hoist = 1;   // epilogue operands are requested in front of the main loop (gemm_kernel.h: HOIST)
 #ifdef VD_TIMELINE
     a.tl = nullptr;
 #endif
@@ -684,17 +502,16 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
         static const char* ov_env = getenv("VD_GEMM_TILE");
         int ov = g_override.load(std::memory_order_relaxed);
         if (ov < 0 && ov_env) ov = atoi(ov_env);
-        const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T256x128 || ov == T128x256 || ov == T128x256b || ov == T128x128d ||
-                              ov == T128x128q || ov == T128x128w8q || ov == T256x256 || ov == T256x128m || ov == T128x128m;
-        if (ov >= 0 && ov < T_COUNT && (d.act != VD_ACT_GEGLU || geglu_ok) && !(d.M < 96 || d.N < 96)) {
+        const bool geglu_ok = ov == T128x128 || ov == T128x128w8 || ov == T128x128d;
+        if (ov >= 0 && ov < T_COUNT && cfg_built(ov) && (d.act != VD_ACT_GEGLU || geglu_ok) && !(d.M < 96 || d.N < 96)) {
             cfg = (TileCfg)ov;
             // re-plan the split for the forced tile: fill the chip once (one block per CU for the 1-block-per-CU tiles)
             nsplit = 1;
             if (d.split_k <= 0 && can_split && a.kt_total >= 32) {
                 const int tiles = ((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * zb;
-                const int slots = (cfg == T128x128 || cfg == T128x128d || cfg == T128x128q) ? 512
-                                  : (cfg == T128x64 || cfg == T128x64d || cfg == T128x64q) ? 768
-                                  : (cfg == T64x64 || cfg == T64x64d || cfg == T64x64q) ? 1024 : 256;
+                const int slots = (cfg == T128x128 || cfg == T128x128d) ? 512
+                                  : (cfg == T128x64 || cfg == T128x64d) ? 768
+                                  : (cfg == T64x64 || cfg == T64x64d) ? 1024 : 256;
                 nsplit = slots / tiles;
                 if (nsplit < 1) nsplit = 1;
                 if (nsplit > VD_MAX_SPLIT_K / 2) nsplit = VD_MAX_SPLIT_K / 2;
@@ -705,33 +522,14 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     if (d.split_k > 0) nsplit = d.split_k;
     if (nsplit > a.kt_total) nsplit = a.kt_total;
     if (g_override.load(std::memory_order_relaxed) < 0 && !tuned) {
-        // Pipeline-depth variants: 32-deep K tiles in a 4-stage ring ("q" instances: same LDS footprint as 64-deep x 2,
-        // tiles issued 3 ahead) and two 128x160 blocks per CU for the N = 320 layers.  Both won 1-3 % over the forward under
-        // the software-pipelined main loop and LOSE 2 % under the default burst loop (same box: 13.15 vs 13.00 ms), so
-        // they are development switches only: VD_GEMM_VARIANT=q forces the q instances, =h also the 128x160 blocks.
-        static const char* var_env = getenv("VD_GEMM_VARIANT");
-        const char v = var_env ? var_env[0] : '0';
         const int ktps = (a.kt_total + nsplit - 1) / nsplit;
-        if (v == 'h' && cfg == T128x320 && d.N % 160 == 0) cfg = T128x160q;
-        if (v == 'q' || v == 'h') {
-            switch (cfg) {
-                case T128x128: cfg = T128x128q; break;
-                case T128x128w8: cfg = T128x128w8q; break;
-                case T128x320: cfg = T128x320q; break;
-                case T128x160: cfg = T128x160q; break;
-                case T128x64: cfg = T128x64q; break;
-                case T64x64: cfg = T64x64q; break;
-                default: break;
-            }
-        }
         // grids that cannot fill the CUs twice over are latency-bound per block: those get a deeper ring of 64-deep tiles
         // (round 4, tools/probes/gemm_timeline.py: raising the limit to "every block still co-resident" -- 768 blocks of 64x64,
         // 512 of 128x64 -- shortens the K loop of the M = 2048, N = K = 1280 projections from 11.6 to 10.1 us per block, not to
         // half: at 640 blocks x 16 KiB per k-step the loop runs at the L2 -> LDS fill rate, not at one round trip per k-step.
         // Forward unchanged (10.57 vs 10.57 ms), so the limit stays; VD_GEMM_DEEP_MAX moves it.)
         const long grid_blocks = (long)((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * nsplit * zb;
-        static const char* deep_env = getenv("VD_GEMM_DEEP_MAX");
-        const long deep64 = deep_env ? atol(deep_env) : 400, deep128 = deep_env ? atol(deep_env) : 400;
+        const long deep64 = 400, deep128 = 400;
         if (ktps >= 8) {
             if (cfg == T128x64 && grid_blocks <= deep128) cfg = T128x64d;
             else if (cfg == T64x64 && grid_blocks <= deep64) cfg = T64x64d;
@@ -751,13 +549,9 @@ int plan_gemm(const VdGemmDesc* dp, GemmArgs& a, int& cfg_out, int& nsplit_out, 
     if (lnfold) {
         // the LayerNorm fold is a compile-time variant of the kernel, instantiated for these tiles only
         switch (cfg) {
-            case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T64x64d: case T256x256:
-            case T256x128m: case T128x128m: break;
-            case T128x64d: case T128x64q: cfg = T128x64; break;
-            case T64x64q: cfg = T64x64; break;
-            case T128x128q: case T128x128d: cfg = T128x128; break;
-            case T128x128w8q: cfg = T128x128w8; break;
-            case T128x320q: case T128x160: case T128x160q: case T128x320b: case T128x320b32: case T256x320: case T256x320q: cfg = T128x320; break;
+            case T128x128: case T128x64: case T64x64: case T128x128w8: case T128x64w8: case T128x320: case T64x64d: break;
+            case T128x64d: cfg = T128x64; break;
+            case T128x128d: cfg = T128x128; break;
             default: cfg = (d.act == VD_ACT_GEGLU) ? T128x128w8 : T128x128; break;
         }
     }
@@ -800,27 +594,13 @@ extern "C" int vd_gemm_skip_ok(const VdGemmDesc* dp) {
     return c == T_COUNT + 12 ? 1 : 0;
 }
 
-extern "C" int vd_gemm_groupnorm_ok(const VdGemmDesc* dp, int conv3x3_wstream) {
-    if (dp == nullptr) return 0;
-    VdGemmDesc tmp = *dp;
-    tmp.flags |= VD_EPI_GROUPNORM;
-    GemmArgs a;
-    ConvHaloArgs halo;
-    int c = 0, n = 1;
-    if (plan_gemm(&tmp, a, c, n, &halo) != VD_OK) return 0;
-    RnArgs rn;
-    int nt = 0;
-    if (!groupnorm_reduce_plan(a, rn, &nt)) return 0;
-    return (conv3x3_wstream || n > 1) ? 1 : 0;   // the weight-streaming conv always runs split + reduce
-}
-
 // launches whose part 2 can accumulate VdGemmDesc.row_sums: an unsplit gemm_f16_kernel (not the halo conv, not a reduce kernel)
 // with the fast write-out path (vector-aligned fp16 output, residual OR row vector) and a power-of-two number of 16-byte
 // segments per tile row
 static bool row_sums_ok(const GemmArgs& a, int cfg, int nsplit) {
     const VdGemmDesc& d = a.d;
     if (cfg >= T_COUNT || nsplit > 1 || d.act == VD_ACT_GEGLU) return false;
-    if (d.flags & (VD_EPI_OUT_F32 | VD_EPI_GROUPNORM | VD_EPI_BIAS_ALONG_M)) return false;
+    if (d.flags & (VD_EPI_OUT_F32 | VD_EPI_BIAS_ALONG_M)) return false;
     if ((d.flags & VD_EPI_RESIDUAL) && (d.flags & VD_EPI_ROWVEC)) return false;
     if ((d.N & 7) || (d.ldc & 7) || (d.ldr & 7)) return false;
     const int ch = kCfg[cfg].bn / 8;
@@ -871,6 +651,10 @@ extern "C" int vd_gemm_tune_clear(void) {
     return VD_OK;
 }
 extern "C" int vd_gemm_set_override(int tile_cfg) {
+    if (tile_cfg >= 0 && !cfg_built(tile_cfg)) {
+        vd_set_error("vd_gemm_set_override: tile configuration %d is not instantiated", tile_cfg);
+        return VD_ERR_UNSUPPORTED;
+    }
     g_override.store(tile_cfg, std::memory_order_relaxed);
     return VD_OK;
 }
@@ -904,47 +688,31 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         return VD_ERR_UNSUPPORTED;
     }
     if (d.flags & VD_EPI_LN_SUMS) VD_REQUIRE((d.flags & VD_EPI_LNFOLD) && d.ln_stats != nullptr, "vd_gemm_f16: VD_EPI_LN_SUMS needs VD_EPI_LNFOLD and ln_stats");
-    if (d.flags & VD_EPI_GROUPNORM) {
-        RnArgs rn;
-        int nt = 0;
-        a.d.sync = nullptr;
-        halo.g.d.sync = nullptr;
-        VD_REQUIRE(nsplit > 1 && groupnorm_reduce_plan(a, rn, &nt),
-                   "vd_gemm_f16: VD_EPI_GROUPNORM needs a launch that is split over K and a panel that fits (vd_gemm_groupnorm_ok)");
-    }
+    // (VD_EPI_GROUPNORM of ABI 5-7 -- the consuming GroupNorm inside the kernel that sums split-K slabs -- measured neutral and was
+    // removed with ABI 8: the flag bits and the gn_* descriptor fields are reserved)
+    VD_REQUIRE(!(d.flags & (VD_EPI_GROUPNORM | VD_EPI_GN_SILU)), "vd_gemm_f16: VD_EPI_GROUPNORM was removed in ABI 8 (run the GroupNorm from out_stats)");
     const int zb = d.batch;
-    static const char* nt_env = getenv("VD_GEMM_NT");  // development switch, read once per process
-    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
+    a.nt_store = 1;   // non-temporal stores of write-once outputs
     {   // which operand an XCD keeps in its private L2 (see the tile mapping in gemm_kernel.h): fabric bytes of the two orders
-        static const char* mf_env = getenv("VD_GEMM_MFAST");   // development switch: 0 = always n fastest, 1 = always m fastest
         const int tiles_m = cfg >= T_COUNT ? halo.g.tiles_m : a.tiles_m, tiles_n = cfg >= T_COUNT ? halo.g.tiles_n : a.tiles_n;
         const double wbytes = (double)d.N * d.K * 2.0, abytes = (double)a.a0_bytes + a.a1_bytes;
         const double runs = (double)tiles_m * tiles_n / 8.0;   // tiles per XCD
         // n fastest: an XCD covers min(tiles_n, runs) column panels and runs / tiles_n (>= 1) row panels
         const double nfast = 8.0 * wbytes * (runs < tiles_n ? runs / tiles_n : 1.0) + abytes * (runs < tiles_n ? tiles_n / runs : 1.0);
         const double mfast = 8.0 * abytes * (runs < tiles_m ? runs / tiles_m : 1.0) + wbytes * (runs < tiles_m ? tiles_m / runs : 1.0);
-        static const char* thr_env = getenv("VD_GEMM_MFAST_THR");
-        static const double thr = thr_env ? atof(thr_env) : 0.8;
-        a.mfast = (zb == 1 && mfast < thr * nfast) ? 1 : 0;
-        if (mf_env) a.mfast = (mf_env[0] == '1' && zb == 1) ? 1 : 0;
+        a.mfast = (zb == 1 && mfast < 0.8 * nfast) ? 1 : 0;
         halo.g.mfast = a.mfast;
     }
     if (cfg >= T_COUNT) {   // halo-resident 3x3 convolution; split-K slabs go through the same reduce kernel
         halo.g.nt_store = a.nt_store;
-        if (nsplit <= 1 || 2l * halo.g.tiles_m * halo.g.tiles_n > VD_GEMM_SYNC_INTS) halo.g.d.sync = nullptr;
-        {   // ticketed split: blocks are dispatched round-robin over the 8 XCDs in linear order (x fastest); with a tile count
-            // that is a multiple of 8 every split of a tile (same blockIdx.x) lands on XCD blockIdx.x % 8
-            // opt-in: the L2-scope exchange is only safe while block b is dispatched to XCD b % 8, which HIP does not
-            // promise (partition modes, CU masks); the default ticketed path exchanges at agent scope
-            static const char* loc_env = getenv("VD_HALO_XCD_LOCAL");   // development switch: 1 = exchange through the XCD's L2
-            const bool want = loc_env && loc_env[0] == '1';
-            halo.g.xcd_local = (want && halo.g.d.sync != nullptr && ((long)halo.g.tiles_m * halo.g.tiles_n) % 8 == 0) ? 1 : 0;
-        }
+        // (the channel-chunk split is reduced by the reduce launch: the ticketed in-kernel reduction of rounds 4-5 -- VD_HALO_FIXUP,
+        // with or without the XCD-local exchange -- measured equal at a 2-way split and 9 us slower per conv at 4-way; removed in round 6)
+        halo.g.d.sync = nullptr;
+        halo.g.xcd_local = 0;
         rc = vd_conv_halo_launch(&halo, cfg - T_COUNT, nsplit, stream);
         if (rc != VD_OK) return rc;
         if (nsplit > 1 && halo.g.d.sync == nullptr) {   // no ticket counters: slabs + the reduce kernel
             a.d.sync = nullptr;
-            if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
             if (d.out_stats != nullptr) {
                 launch_reduce_stats(a, nsplit, stream);
                 return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
@@ -967,9 +735,9 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
             case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512, 2, 64, 4, true>(a, nsplit, stream); break;
             case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512, 2, 64, 4, true>(a, nsplit, stream); break;
             case T128x320: rc = launch_cfg<128, 320, 32, 160, 512, 2, 64, 2, true>(a, nsplit, stream); break;
-            case T256x128m: rc = launch_cfg<256, 128, 64, 64, 512, 3, 64, 2, true, true>(a, nsplit, stream); break;
-            case T128x128m: rc = launch_cfg<128, 128, 32, 64, 512, 3, 64, 2, true, true>(a, nsplit, stream); break;
-            default: rc = vd_gemm_launch_big(cfg, 1, &a, nsplit, stream); break;   // 256x256 (GEGLU)
+            default:
+                vd_set_error("vd_gemm_f16: tile configuration %d has no LayerNorm-fold instance", cfg);
+                return VD_ERR_UNSUPPORTED;
         }
         return rc;
     }
@@ -979,26 +747,16 @@ extern "C" int vd_gemm_f16(const VdGemmDesc* dp, hipStream_t stream) {
         case T64x64: rc = launch_cfg<64, 64, 32, 32, 256, 2, 64, 2>(a, nsplit, stream); break;
         case T128x128w8: rc = launch_cfg<128, 128, 32, 64, 512, 2, 64, 4>(a, nsplit, stream); break;
         case T128x64w8: rc = launch_cfg<128, 64, 32, 32, 512, 2, 64, 4>(a, nsplit, stream); break;
-        case T256x128: rc = launch_cfg<256, 128, 64, 64, 512, 2, 64, 2>(a, nsplit, stream); break;
-        case T128x256: rc = launch_cfg<128, 256, 64, 64, 512, 2, 64, 2>(a, nsplit, stream); break;
         case T128x320: rc = launch_cfg<128, 320, 32, 160, 512, 2, 64, 2>(a, nsplit, stream); break;
-        case T128x160: rc = launch_cfg<128, 160, 32, 160, 256, 2, 64, 2>(a, nsplit, stream); break;
         case T128x128d: rc = launch_cfg<128, 128, 64, 64, 256, 3, 64, 1>(a, nsplit, stream); break;
         case T128x64d: rc = launch_cfg<128, 64, 64, 32, 256, 3, 64, 2>(a, nsplit, stream); break;
         case T64x64d: rc = launch_cfg<64, 64, 32, 32, 256, 3, 64, 2>(a, nsplit, stream); break;
-        case T128x128q: rc = launch_cfg<128, 128, 64, 64, 256, 4, 32, 2>(a, nsplit, stream); break;
-        case T128x64q: rc = launch_cfg<128, 64, 64, 32, 256, 4, 32, 2>(a, nsplit, stream); break;
-        case T64x64q: rc = launch_cfg<64, 64, 32, 32, 256, 4, 32, 2>(a, nsplit, stream); break;
-        case T128x128w8q: rc = launch_cfg<128, 128, 32, 64, 512, 4, 32, 4>(a, nsplit, stream); break;
-        case T128x320q: rc = launch_cfg<128, 320, 32, 160, 512, 4, 32, 2>(a, nsplit, stream); break;
-        case T128x160q: rc = launch_cfg<128, 160, 32, 160, 256, 4, 32, 2>(a, nsplit, stream); break;
-        case T256x128m: rc = launch_cfg<256, 128, 64, 64, 512, 3, 64, 2, false, true>(a, nsplit, stream); break;
-        case T128x128m: rc = launch_cfg<128, 128, 32, 64, 512, 3, 64, 2, false, true>(a, nsplit, stream); break;
-        default: rc = vd_gemm_launch_big(cfg, 0, &a, nsplit, stream); break;
+        default:
+            vd_set_error("vd_gemm_f16: tile configuration %d is not instantiated", cfg);
+            return VD_ERR_UNSUPPORTED;
     }
     if (rc != VD_OK) return rc;
     if (nsplit > 1 && a.d.sync == nullptr) {
-        if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
         if (d.out_stats != nullptr) {   // plan_stat_rows: batch 1, fp16 output, whole 64-row blocks per image
             launch_reduce_stats(a, nsplit, stream);
             return vd_check_launch("vd_gemm_f16/splitk_reduce_stats");
@@ -1024,7 +782,6 @@ int vd_gemm_normalise(const VdGemmDesc* desc, void* gemm_args_out) {
 int vd_gemm_launch_reduce(const void* gemm_args, int nsplit, hipStream_t stream) {
     const GemmArgs& a = *static_cast<const GemmArgs*>(gemm_args);
     const VdGemmDesc& d = a.d;
-    if (d.flags & VD_EPI_GROUPNORM) return launch_reduce_groupnorm(a, nsplit, stream);
     if (d.out_stats != nullptr) {
         launch_reduce_stats(a, nsplit, stream);
         return vd_check_launch("splitk_reduce_stats");

@@ -529,9 +529,6 @@ constexpr bool gemm_emits_stats();
 template <int BM, int BN, int WM, int WN, int NT, int STAGES, int KB, int OCC, bool LNF = false, bool MID = false>
 __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     static_assert(!MID || (STAGES == 3 && KB == 64), "the mid-barrier loop walks 64-deep tiles through three stages");
-    // wave tiles of 8+ MFMA tiles at two waves per SIMD (256 registers each) cannot hold two fragment sets next to the
-    // accumulators: those instances read the fragments of a k-step right before its MFMAs (the partner wave covers the wait)
-    constexpr int FB = ((WM / 32) * (WN / 32) >= 8 && OCC >= 2) ? 1 : 2;
     static_assert(KB == 64 || KB == 32, "K tile depth");
     static_assert(STAGES >= 2, "LDS ring needs at least two stages");
     constexpr int KROW_BYTES = KB * 2;  // one LDS row of a stage
@@ -556,9 +553,6 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     static_assert((WM / 32) % EP == 0, "epilogue passes must divide the wave tile's 32-row blocks");
     constexpr int EPI_BYTES = (BM / EP) * CS_LD * 2;
     constexpr int D = STAGES - 1;  // prefetch distance in tiles
-    // the pieces of the tile issued in an iteration go into its first PSTEPS k-steps (the last step holds the wait)
-    constexpr int PSTEPS = KS > 2 ? KS - 2 : 1;
-    constexpr int PPS = (LPT + PSTEPS - 1) / PSTEPS;
     static_assert(LPT * (D > 1 ? D - 1 : 1) < 64, "vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -748,7 +742,6 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
         rd_a[ks] = lds_off_kb<KB>(wm * WM + l31, ks * 2 + hi);
         rd_b[ks] = BMP * KROW_BYTES + lds_off_kb<KB>(wn * WN + l31, ks * 2 + hi);
     }
-    f16x8 fa[FB][MI], fb[FB][NI];  // (double-buffered) operand fragments; indices are compile-time after unrolling
     // LayerNorm fold without a statistics pass (d.ln_stats == NULL): every A fragment passes through read_frags exactly once,
     // and a lane's fragments all belong to ONE row per 32-row block (row l31, k-half hi) -- sum and sum of squares of that row
     // are two v_dot2_f32_f16 per register on the way (8 VALU instructions per fragment, issued beside the MFMAs), the other
@@ -791,81 +784,6 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
     // short-K projections has no slack for it: +24 us on the 57 us q/k/v projection of the 64x64 level, +35 us on its
     // GEGLU projection -- as much as the LayerNorm launches the fold removes.  LNF stays a compile-time property of the
     // instantiation so that launches without it carry none of this.
-    constexpr bool lnf = LNF;
-    // one iteration = one K tile.  MODE 0: steady state (issues tile i + D, leaves D - 1 tiles in flight at the wait),
-    // MODE 1: drain (nothing left to issue), MODE 2: last tile (no successor to wait for).
-    auto iteration = [&](auto mode_tag, int i, int cbuf, int nbuf, int ibuf) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const char* st = smem + cbuf * STAGE_BYTES;
-        if constexpr (MODE == 0) issue_begin(kt0 + i + D, ibuf);
-        if constexpr (FB == 1) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                read_frags(st, ks, fa[0], fb[0]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < NMF; ++m) {
-                    if constexpr (MODE == 0) {
-                        if (ks < PSTEPS) {
-#pragma unroll
-                            for (int q = 0; q < PPS; ++q)
-                                if ((q * NMF) / PPS == m && ks * PPS + q < LPT) {
-                                    issue_piece(ks * PPS + q);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                        }
-                    }
-                    const int mi = m / NI, nj = m % NI;
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][nj], fa[0][mi], acc[mi][nj], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (MODE != 2) {
-                if constexpr (MODE == 0) wait_vm<LPT * (D - 1)>();
-                else wait_vm<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        } else {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            // program order of a k-step is pinned with sched_barrier: fragment requests first, then the MFMAs with this
-            // step's DMA pieces in the gaps (hipcc otherwise emits the pieces as one burst behind the MFMAs -- the
-            // matrix pipe idles through it -- and sinks the post-barrier fragment requests behind the first MFMAs)
-            if (ks + 1 < KS) {
-                read_frags(st, ks + 1, fa[nxt], fb[nxt]);
-            } else if constexpr (MODE != 2) {
-                // tile i + 1 must have landed (own pieces), every wave must be done reading tile i - (STAGES - 2) ... i
-                if constexpr (MODE == 0) wait_vm<LPT * (D - 1)>();
-                else wait_vm<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");  // LDS reads below must not be hoisted above the barrier
-                read_frags(smem + nbuf * STAGE_BYTES, 0, fa[nxt], fb[nxt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < NMF; ++m) {
-                if constexpr (MODE == 0) {
-                    if (ks < PSTEPS) {
-#pragma unroll
-                        for (int q = 0; q < PPS; ++q)
-                            if ((q * NMF) / PPS == m && ks * PPS + q < LPT) {
-                                issue_piece(ks * PPS + q);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                    }
-                }
-                const int mi = m / NI, nj = m % NI;
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][nj], fa[cur][mi], acc[mi][nj], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // the MFMAs of this step stay in front of the next step's wait / barrier
-        }
-        }  // FB == 2
-    };
-
     if constexpr (MID) {
         if (nk > 0) {
             auto issue_tile = [&](int t, int buf) {
@@ -916,13 +834,13 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             }
         }
     } else {
-#ifndef VD_GEMM_PIPELINED
-    // ---- main loop (default): every K tile = { wait for the tile, barrier, issue the tile D ahead as ONE burst, then the
+    // ---- main loop: every K tile = { wait for the tile, barrier, issue the tile D ahead as ONE burst, then the
     // compiler-scheduled ds_read / MFMA stream of the landed tile }.  The burst gives a DMA the longest possible lead (a
     // whole iteration per stage of distance), and hipcc's own interleave of the fragment reads with the MFMAs (fine
-    // lgkmcnt ladders) beats a hand-pinned order: the software-pipelined variant below (fragments double-buffered across
-    // the barrier, DMA pieces in the MFMA gaps, order pinned with sched_barrier) measured 4 % SLOWER over the UNet forward on
-    // the same box (13.50 vs 12.95 ms) although it wins by 3-4 % on a back-to-back micro-benchmark of one shape.
+    // lgkmcnt ladders) beats a hand-pinned order: a software-pipelined variant (fragments double-buffered across the barrier,
+    // DMA pieces in the MFMA gaps, order pinned with sched_barrier; -DVD_GEMM_PIPELINED of rounds 1-5, removed in round 6)
+    // measured 4 % SLOWER over the UNet forward on the same box (13.50 vs 12.95 ms; again 10.43 vs 10.50 in round 5) although
+    // it won by 3-4 % on a back-to-back micro-benchmark of one shape.
     if (nk > 0) {
 #pragma unroll
         for (int j = 0; j < D; ++j)
@@ -961,37 +879,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_f16_kernel(const GemmArgs p) {
             ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
         }
     }
-#else
-    // ---- prologue: the first D tiles in one burst, then the fragments of k-step 0 of tile 0
-    if (nk > 0) {
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (j < nk) {
-                issue_begin(kt0 + j, j);
-#pragma unroll
-                for (int pc = 0; pc < LPT; ++pc) issue_piece(pc);
-            }
-        if (nk >= D) wait_vm<LPT * (D - 1)>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (FB == 2) read_frags(smem, 0, fa[0], fb[0]);
-        int cbuf = 0, ibuf = D % STAGES;
-        int i = 0;
-        auto next = [](int b) { return b + 1 == STAGES ? 0 : b + 1; };
-        for (; i + D < nk; ++i) {
-            iteration(std::integral_constant<int, 0>{}, i, cbuf, next(cbuf), ibuf);
-            cbuf = next(cbuf);
-            ibuf = next(ibuf);
-        }
-        for (; i + 1 < nk; ++i) {
-            iteration(std::integral_constant<int, 1>{}, i, cbuf, next(cbuf), ibuf);
-            cbuf = next(cbuf);
-        }
-        iteration(std::integral_constant<int, 2>{}, i, cbuf, 0, 0);
-    }
-#endif
     }   // !MID
+    constexpr bool lnf = LNF;
     wait_vm<0>();
     __syncthreads();  // every wave is done with the stages: the epilogue tile re-uses that LDS
     VD_TL(2);   // main loop done
@@ -1320,4 +1209,3 @@ int launch_cfg(const GemmArgs& a, int nsplit, hipStream_t stream) {
 }  // namespace
 
 // one-wave-per-SIMD instances (gemm_big.hip); cfg = TileCfg value
-int vd_gemm_launch_big(int cfg, int variant, const void* args, int nsplit, hipStream_t stream);

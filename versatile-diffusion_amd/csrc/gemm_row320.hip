@@ -540,12 +540,9 @@ extern "C" int vd_gemm_row320_f16(const void* x, const void* w, const void* bias
 #ifdef VD_TIMELINE
     a.tl = g_timeline_row;
 #endif
-    static const char* nt_env = getenv("VD_GEMM_NT");
-    a.nt_store = nt_env ? (nt_env[0] != '0') : 1;
-    // more than one column group and no residual: one block per row block walks them all (development switch VD_ROW320_MULTI=0:
-    // one block per (row block, column group))
-    static const char* multi_env = getenv("VD_ROW320_MULTI");
-    const bool multi = N > RG_C && N <= 4096 && res == nullptr && !(multi_env && multi_env[0] == '0');
+    a.nt_store = 1;   // non-temporal stores of write-once outputs
+    // more than one column group and no residual: one block per row block walks them all
+    const bool multi = N > RG_C && N <= 4096 && res == nullptr;
     if (multi) return layernorm ? launch_rowgemm<true, true>(a, stream) : launch_rowgemm<false, true>(a, stream);
     return layernorm ? launch_rowgemm<true, false>(a, stream) : launch_rowgemm<false, false>(a, stream);
 }

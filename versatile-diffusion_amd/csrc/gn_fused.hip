@@ -558,14 +558,8 @@ static int gn_apply_launch(const char* who, GnApplyArgs& a, const void* x0, int 
     a.R = 256 / a.TC;
     a.npos = (C8 + a.TC - 1) / a.TC;
     // ~16K elements per block (the optimum the round-3 apply kernel measured), whole row-lane trips
-    static const char* chunk_env = getenv("VD_GN_CHUNK");   // development switch: elements per block
-    static const int chunk = chunk_env ? atoi(chunk_env) : 8192;   // 8192: measured best with the light prologue (16384: +0.02 ms, 32768: +0.12)
-    static const char* schunk_env = getenv("VD_GN_SUMS_CHUNK");   // the same for the form that folds the producers' sums in its prologue
-    static const int schunk = schunk_env ? atoi(schunk_env) : 8192;
-    static const char* srows_env = getenv("VD_GN_SUMS_MINROWS");   // every block of the SUMS form reads its image's sums (16 bytes per channel):
-    static const int srows = srows_env ? atoi(srows_env) : 0;      // at least this many rows per block bound that overhead for wide tensors
-    int rpc = (a.table ? chunk : schunk) / C;
-    if (!a.table && rpc < srows) rpc = srows;
+    constexpr int chunk = 8192;   // elements per block: measured best with the light prologue (16384: +0.02 ms per forward, 32768: +0.12)
+    int rpc = chunk / C;
     if (rpc < 1) rpc = 1;
     rpc = ((rpc + a.R - 1) / a.R) * a.R;
     if (rpc > HW) rpc = HW;

@@ -478,18 +478,9 @@ extern "C" int vd_xattn_f16(const void* x, const void* wq, const void* bq, const
     // development switch VD_XATTN_VAR: 1 = early K/V tile 0 (measured neutral: 42.6 / 24.3 / 32.7 us vs 43.3 / 24.1 / 30.4 at the
     // 64x64 / 32x32 / 16x16 levels), 2 = head dim 40 with the old 3-stage, 2-blocks-per-CU pipeline (43.3 us vs 38.3 at 3 blocks:
     // what hides the chunk latency is a third resident block, not a deeper pipeline)
-    static const char* var_env = getenv("VD_XATTN_VAR");
-    const int var = var_env ? atoi(var_env) : 0;
     switch (D) {
-        case 40:
-            if (var == 1) return launch_xattn<40, 2, true, 2>(a, stream);
-            if (var == 2) return launch_xattn<40, 3, false, 2>(a, stream);
-            return launch_xattn<40, 2, false, 3>(a, stream);
-        case 80:
-            if (var == 1) return launch_xattn<80, 2, true, 2>(a, stream);
-            return launch_xattn<80, 2, false, 2>(a, stream);
-        default:
-            if (var == 1) return launch_xattn<160, 3, true, 1>(a, stream);
-            return launch_xattn<160, 4, false, 1>(a, stream);
+        case 40: return launch_xattn<40, 2, false, 3>(a, stream);
+        case 80: return launch_xattn<80, 2, false, 2>(a, stream);
+        default: return launch_xattn<160, 4, false, 1>(a, stream);
     }
 }

@@ -105,7 +105,7 @@ class Conv2d(nn.Conv2d, PackCache):
         if k == 3 and s == 1 and p == 1 and pad_hi is None and cin % 64 == 0 and x.shape[-1] % 64 == 0 and self.out_channels % 32 == 0:
             small = (ops.WSTREAM and ups == 0 and x.shape[1] == 8 and x.shape[2] == 8 and x.shape[0] % 2 == 0
                      and self.out_channels % 256 == 0)   # 8x8 level: the layer is its weight stream
-            if small or (ops.WREG and (x.shape[2] << ups) % 16 == 0):
+            if small:
                 epi = dict(epi, w_stream=self._w_stream())
         return ops.conv2d_nhwc(x, w, b, ksize=k, stride=s, pad=p, ups=ups, x1=x1, pad_hi=pad_hi, **epi)
 

@@ -163,14 +163,10 @@ class ResBlock(TimestepBlock, PackCache):
         # every tensor between the layers of the data flow feeds a GroupNorm (the next block's, or a later skip concat): its
         # producer emits the per-channel statistics (want_stats), the norms read them instead of measuring their input
         h = self.in_layers[0](x, x1=skip, silu=True)
-        # conv1 -> GroupNorm -> SiLU: where the conv runs split over K (32x32 level and below) the kernel that sums the slabs
-        # normalises in place (the raw conv output is consumed by this norm only); else the conv emits the statistics
+        # conv1 -> GroupNorm -> SiLU: the conv (or the kernel that sums its split-K slabs) emits the statistics the norm reads
         n2 = self.out_layers[0]
-        g2, b2 = n2._w()
-        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W if emb_out is not None else 0, bias=bias1, want_stats=True,
-                              gn=(g2, b2, n2.num_groups, n2.eps, True))
-        if not getattr(h, "_vd_normalized", False):
-            h = n2(h, silu=True)
+        h = self.in_layers[2](h, rowvec=emb_out, rows_per_batch=H * W if emb_out is not None else 0, bias=bias1, want_stats=True)
+        h = n2(h, silu=True)
         if fork:
             main.wait_stream(side)
         elif isinstance(self.skip_connection, nn.Identity):

@@ -55,7 +55,6 @@ PROTOTYPES = {
     "vd_gemm_workspace_bytes": (_Z, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "vd_gemm_stat_rows": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int)]),
-    "vd_gemm_groupnorm_ok": (_I, [ctypes.POINTER(VdGemmDesc), _I]),
     "vd_gemm_skip_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_gemm_row_sums_ok": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
@@ -65,9 +64,6 @@ PROTOTYPES = {
     "vd_gemm_wstream_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
     "vd_conv3x3_wstream_supported": (_I, [ctypes.POINTER(VdGemmDesc)]),
     "vd_conv3x3_wstream_set_variant": (_I, [_I, _I]),
-    "vd_conv3x3_wreg_f16": (_I, [ctypes.POINTER(VdGemmDesc), _P, _P]),
-    "vd_conv3x3_wreg_plan": (_I, [ctypes.POINTER(VdGemmDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
-    "vd_conv3x3_wreg_set_blocks": (_I, [_I]),
     "vd_gemm_config_name": (ctypes.c_char_p, [_I]),
     "vd_gemm_num_configs": (_I, []),
     "vd_gemm_set_override": (_I, [_I]),

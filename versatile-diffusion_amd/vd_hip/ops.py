@@ -112,10 +112,6 @@ def workspace(nbytes, device, tag="ws"):
 
 SYNC_INTS = 16384   # VD_GEMM_SYNC_INTS
 FIXUP_DEFAULT = os.environ.get("VD_GEMM_FIXUP", "0") == "1"
-# opt-in (VD_HALO_FIXUP=1): the halo conv reduces its channel-chunk split in-kernel through ticket counters instead of the
-# reduce launch.  Correct, not faster: equal at a 2-way split, 9 us slower per conv at 4-way, forward 11.98 vs 11.93 ms.
-HALO_FIXUP_MAXSPLIT = int(os.environ.get("VD_HALO_FIXUP_MAXSPLIT", "32"))   # ... only for splits up to this factor
-HALO_FIXUP = os.environ.get("VD_HALO_FIXUP", "0") == "1"   # (VD_HALO_XCD_LOCAL=1 adds the L2-scope exchange: opt-in, it relies on block -> XCD placement)
 
 
 def sync_counters(device):
@@ -181,7 +177,7 @@ def repeat_batch(t, repeat):
 def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, out=None, M=None, N=None, K=None,
          conv=None, act=ACT_NONE, alpha=1.0, out_f32=False, bias_along_m=False, batch=1, strides=(0, 0, 0, 0),
          lda0=0, lda1=0, ldw=0, ldc=0, ldr=0, c0=0, c1=0, split_k=0, out_shape=None, colsum=None, ln_eps=0.0, fixup=None,
-         want_stats=False, stat_img_rows=0, w_stream=None, gn=None, skip=None, row_sums=None, ln_sums=None):
+         want_stats=False, stat_img_rows=0, w_stream=None, skip=None, row_sums=None, ln_sums=None):
     """out = epilogue(A @ W^T); see VdGemmDesc in include/vd_hip.h.
 
     conv = dict(Hin, Win, Hout, Wout, ksize, stride, pad, ups) selects the implicit-GEMM gather.
@@ -195,9 +191,6 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     launch can emit them, else the attribute is absent.  stat_img_rows: rows of one sample for plain matrices (conv: Hout*Wout).
     w_stream: the same conv weights in MFMA-fragment order (pack.pack_conv_weight_stream); 3x3 convolutions on 8x8 images then
     run on the weight-streaming kernel (vd_conv3x3_wstream_f16) where its geometry fits.
-    gn = (gamma, beta, groups, eps, silu): the GroupNorm (+ SiLU) that consumes this output.  Where the launch is split over K
-    the kernel that sums the slabs normalises in place (VD_EPI_GROUPNORM): the returned tensor is then the NORMALISED one and
-    carries `_vd_normalized = True`; otherwise gn is ignored (the caller runs the norm) and want_stats applies.
     skip = (s0, s1 or None, w_skip [N, C_s0 + C_s1]): a 1x1 convolution of cat(s0, s1) on the output grid folded into this 3x3
     convolution as extra K (ResBlock's skip_connection(x) + h; its bias belongs into `bias`).  Returns None WITHOUT launching
     when the planned launch cannot take it (vd_gemm_skip_ok): the caller then runs the 1x1 convolution itself.
@@ -209,7 +202,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
     _req(a0, "a0"); _req(a1, "a1"); _req(w, "w"); _req(bias, "bias"); _req(rowvec, "rowvec"); _req(res, "res")
     _req(colsum, "colsum", torch.float32); _req(row_sums, "row_sums", torch.int64); _req(ln_sums, "ln_sums", torch.int64)
     if out is not None:   # a re-used output tensor must not keep the statistics of what it held before
-        for attr in ("_vd_stats", "_vd_normalized", "_vd_rowsums"):
+        for attr in ("_vd_stats", "_vd_rowsums"):
             if hasattr(out, attr):
                 delattr(out, attr)
     # (the plain N = 320 projections measure equal on both kernels -- 24.9 vs 24.2 us: with one 128-row block per CU in
@@ -298,25 +291,12 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             d.skip_lda0, d.skip_lda1, d.skip_ldw = d.skip_c0, d.skip_c1, int(wsk.shape[-1])
             if not lib().vd_gemm_skip_ok(ctypes.byref(d)):
                 return None
-    gn_on = False
-    if gn is not None and GN_REDUCE and res is None and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
-        _req(gn[0], "gn gamma"); _req(gn[1], "gn beta")
-        d.gn_gamma, d.gn_beta, d.gn_groups, d.gn_eps = gn[0].data_ptr(), gn[1].data_ptr(), int(gn[2]), float(gn[3])
-        gn_on = True
-        gn_flags = EPI_GROUPNORM | (EPI_GN_SILU if gn[4] else 0)
-        if not stat_img_rows and conv is not None:
-            d.stat_img_rows = int(d.Hout) * int(d.Wout)
-        elif stat_img_rows:
-            d.stat_img_rows = int(stat_img_rows)
     if w_stream is not None and WSTREAM and colsum is None and (skip is None or skip_stream) and lib().vd_conv3x3_wstream_supported(ctypes.byref(d)):
         _req(w_stream, "w_stream")
         if skip_stream:
             d.skip_a0, d.skip_a1, d.skip_w = s0.data_ptr(), (s1.data_ptr() if s1 is not None else None), wsk_stream.data_ptr()
             d.skip_lda0, d.skip_lda1 = d.skip_c0, d.skip_c1
         d.split_k = int(split_k)
-        fused_gn = gn_on and bool(lib().vd_gemm_groupnorm_ok(ctypes.byref(d), 1))
-        if fused_gn:
-            d.flags = flags | gn_flags
         # the launcher's own split (0: the whole-K kernel, no slabs at all) sizes the workspace -- not the 32-slab upper bound
         pns = ctypes.c_int(0)
         _check(lib().vd_conv3x3_wstream_plan(ctypes.byref(d), ctypes.byref(pns)))
@@ -324,7 +304,7 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             d.split_k = pns.value
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
         stats = None
-        if want_stats and not fused_gn:
+        if want_stats:
             sbuf = torch.empty((int(M) // 64, n_out, 2), dtype=torch.float32, device=a0.device)
             d.out_stats = sbuf.data_ptr()
             stats = ChanStats(sbuf, 1, n_out, 64)
@@ -336,8 +316,6 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
             _check(lib().vd_conv3x3_wstream_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
         if stats is not None:
             out._vd_stats = stats
-        if fused_gn:
-            out._vd_normalized = True
         return out
     if (w_stream is not None and GEMM_WSTREAM and conv is None and a1 is None and colsum is None and rowvec is None and skip is None
             and not want_stats and max(batch, 1) == 1 and lib().vd_gemm_wstream_supported(ctypes.byref(d))):
@@ -358,38 +336,6 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         if stats is not None:
             out._vd_stats = stats
         return out
-    if w_stream is not None and WREG and skip is None and colsum is None and conv is not None and conv.get("ksize", 1) == 3:
-        # weights-in-registers 3x3 convolution on 128-pixel patches (conv_wreg_kernel.h): plan first (split factor -> workspace,
-        # rows per statistics partial), then launch
-        d.stat_img_rows = int(d.Hout) * int(d.Wout)
-        d.ws = 1   # planning only: a split is allowed
-        sup, pns, prow = ctypes.c_int(0), ctypes.c_int(1), ctypes.c_int(0)
-        _check(lib().vd_conv3x3_wreg_plan(ctypes.byref(d), ctypes.byref(sup), ctypes.byref(pns), ctypes.byref(prow)))
-        d.ws = None
-        if sup.value and (M >= WREG_MIN_M):
-            _req(w_stream, "w_stream")
-            if pns.value > 1:
-                d.split_k = pns.value
-                d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
-            else:
-                d.split_k = 1
-            stats = None
-            if want_stats and prow.value > 0:
-                hw = int(d.Hout) * int(d.Wout)
-                sbuf = torch.empty((int(M) // prow.value, n_out, 2), dtype=torch.float32, device=a0.device)
-                d.out_stats = sbuf.data_ptr()
-                stats = ChanStats(sbuf, hw // prow.value, n_out, hw)
-            extra = (float(M) * n_out if res is not None else 0.0) + (float(rowvec.numel()) if rowvec is not None else 0.0)
-            nm = "conv3x3_wreg_kernel"
-            if PROFILE_SHAPES:
-                nm += " M=%d N=%d K=%d split=%d" % (M, N, K, pns.value)
-            a_elems = float(conv["B"]) * conv["Hin"] * conv["Win"] * (d.c0 + d.c1)
-            with _Timed(nm, 2.0 * M * N * K, 2.0 * (a_elems + float(N) * K + float(M) * n_out + extra)):
-                _check(lib().vd_conv3x3_wreg_f16(ctypes.byref(d), _ptr(w_stream), _stream()))
-            if stats is not None:
-                out._vd_stats = stats
-            return out
-        d.stat_img_rows = 0
     # split-K (fp32 slabs + reduce) is the library's answer to small-M / deep-K problems: ask its planner first so
     # the workspace is sized for the split factor it will actually use
     name, d.ws = "gemm", None
@@ -400,17 +346,11 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         d.ws = None
         if plan_ns.value > 1:
             d.split_k = plan_ns.value
-            # in-kernel reductions (ticket counters of the halo conv, conv_halo_kernel.h; last-arriver fix-up of
-            # gemm_f16_kernel) are opt-in: the reduce launch measured faster for both
+            # the last-arriver fix-up of gemm_f16_kernel is opt-in: the reduce launch measured faster (the halo conv always takes it)
             halo = plan_cfg.value >= lib().vd_gemm_num_configs()
-            use_sync = (HALO_FIXUP and plan_ns.value <= HALO_FIXUP_MAXSPLIT) if halo else (FIXUP_DEFAULT if fixup is None else fixup)
+            use_sync = (not halo) and (FIXUP_DEFAULT if fixup is None else fixup)
             d.sync = sync_counters(a0.device).data_ptr() if use_sync else None
             d.ws = workspace(lib().vd_gemm_workspace_bytes(ctypes.byref(d)), a0.device, "gemm").data_ptr()
-    fused_gn = False
-    if gn_on and plan_ns.value > 1 and d.sync is None and lib().vd_gemm_groupnorm_ok(ctypes.byref(d), 0):
-        fused_gn = True
-        d.flags = flags | gn_flags
-        want_stats = False
     stats = None
     if want_stats and not out_f32 and act != ACT_GEGLU and colsum is None and max(batch, 1) == 1:
         d.stat_img_rows = int(stat_img_rows)
@@ -447,8 +387,6 @@ def gemm(a0, w, *, a1=None, bias=None, rowvec=None, rows_per_batch=0, res=None, 
         _check(lib().vd_gemm_f16(ctypes.byref(d), _stream()))
     if stats is not None:
         out._vd_stats = stats
-    if fused_gn:
-        out._vd_normalized = True
     if rs_on:
         out._vd_rowsums = row_sums
     return out
@@ -517,8 +455,6 @@ def rowsum_take(rows, device):
 
 
 SKIP_FOLD = os.environ.get("VD_SKIP_FOLD", "1") != "0"   # ResBlock skip 1x1 convolution as extra K of the second 3x3 conv
-WREG = os.environ.get("VD_WREG", "0") == "1"   # 3x3 convolutions on the weights-in-registers kernel where its geometry fits
-WREG_MIN_M = int(os.environ.get("VD_WREG_MIN_M", "0"))
 GEMM_WSTREAM = os.environ.get("VD_GEMM_WSTREAM", "1") != "0"   # long-K small-M Linear layers on gemm_wstream_kernel (FeedForward out at 16x16 / 8x8)
 WSTREAM = os.environ.get("VD_WSTREAM", "1") != "0"   # development switch: 0 = the 8x8-level 3x3 convolutions stay on gemm_f16_kernel
 ROW320 = os.environ.get("VD_GEMM_ROW320", "1") != "0"   # development switch: 0 = the K = 320 projections stay on gemm_f16_kernel
@@ -776,10 +712,6 @@ def groupnorm_silu(x, gamma, beta, *, x1=None, groups=32, eps=1e-5, silu=True, o
 # VD_GN_STATS=0: every GroupNorm measures its input itself (rounds 1-3: slab kernel or partial + apply); default: statistics
 # come from the producers' epilogues where they emit them (csrc/gn_fused.hip)
 GN_STATS = os.environ.get("VD_GN_STATS", "1") != "0"
-# opt-in (VD_GN_REDUCE=1): conv -> GroupNorm -> SiLU of split launches normalised inside the kernel that sums the slabs
-# (VD_EPI_GROUPNORM).  Correct (test_conv_groupnorm_fused_in_the_reduce) and measured neutral: the panel kernel takes 23.5 us
-# against 13.1 (reduce + statistics) + 9.2 (single-launch norm) -- narrow slabs read partial cache lines (profiles/HISTORY.md)
-GN_REDUCE = os.environ.get("VD_GN_REDUCE", "0") == "1"
 GN_FUSED_MAX = int(os.environ.get("VD_GN_FUSED_MAX", "2700000"))   # the 16x16 and 8x8 levels (measured: -0.07 ms per forward; 5.3 M: neutral)
 GN_FORM = os.environ.get("VD_GN_FORM", "table")   # table: vd_gn_table_f32 + vd_gn_apply_table_f16; fused: vd_groupnorm_from_stats_f16
 
