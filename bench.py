@@ -24,6 +24,8 @@ The JSON line also carries
   cpu_baseline  -- the CPU fp32 oracle (oracle/vd_oracle.py, kind "port") timed on this host on a bounded sample
   other_workloads -- (default t2i run at N = 1 only) BASELINE configs[2..4] through the same code path, 1 warm-up + 2 timed
                    batches each, OUTSIDE the timed region of the headline value: images/s and ms per batch per workload
+  box_calibration -- how fast THIS box is (the pool spreads +-4 %): vd_gemm_f16 at 8192^3 and a 256 MB copy, outside the
+                   timed region, with the ratio to the round's evidence box
 """
 import argparse
 import json
@@ -256,6 +258,51 @@ def graph_step_ms(net, sampler, wl, batch, steps, device, reps=20):
     return e0.elapsed_time(e1) / reps
 
 
+# reference values of box_calibration on the round-6 evidence box (profiles/r06_bench.json): the `ratio` fields of a later line say
+# how fast THAT box is against it -- boxes of this pool spread +-4 %, more than a round's gain
+CAL_REF = {"gemm_8192_tflops": None, "copy_256mb_tbps": None}
+
+
+def box_calibration(device):
+    """How fast is this box?  Outside every timed region, ~0.3 s: the library's own fp16 GEMM at 8192^3 (MFMA rate under power: what
+    the chip sustains on this box today) and a 256 MB device-to-device copy (memory side).  A driver number divided by these is
+    comparable across boxes and rounds; `ratio` is against CAL_REF where that is filled in."""
+    from vd_hip import ops
+    n = 8192
+    a = torch.randn(n, n, device=device, dtype=torch.float16)
+    w = torch.randn(n, n, device=device, dtype=torch.float16) * 0.02
+    for _ in range(2):
+        ops.gemm(a, w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(6):
+        ops.gemm(a, w)
+    e1.record()
+    torch.cuda.synchronize()
+    g_ms = e0.elapsed_time(e1) / 6
+    del a, w
+    src = torch.empty(256 << 20, dtype=torch.uint8, device=device).fill_(7)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    c_ms = e0.elapsed_time(e1) / 10
+    del src, dst
+    out = {"gemm_8192_tflops": round(2.0 * n ** 3 / g_ms / 1e9, 1), "gemm_8192_ms": round(g_ms, 3),
+           "copy_256mb_tbps": round(2.0 * (256 << 20) / c_ms / 1e9, 3), "copy_256mb_ms": round(c_ms, 4),
+           "note": "vd_gemm_f16 at 8192^3 (random data) and a 256 MB device-to-device copy (read + write bytes), outside the timed region"}
+    ratios = {k: round(out[k] / v, 4) for k, v in CAL_REF.items() if v}
+    if ratios:
+        out["ratio_to_r06_evidence_box"] = ratios
+    return out
+
+
 def cpu_baseline_leg(net, device):
     """CPU fp32 oracle on a bounded sample: one CFG-batch-2 UNet forward (64x64 latent, L=77) and one 32x32-latent
     VAE decode (scaled x4 to 64x64 by area); extrapolated to images/sec at 50 steps.  Threads are pinned (VD_CPU_THREADS,
@@ -444,6 +491,15 @@ def main():
                     json.dump(table, f, indent=1, sort_keys=True)
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline_leg(net, device)
+        try:
+            out["box_calibration"] = box_calibration(device)
+            cal = out["box_calibration"]
+            if "unet_forward_ms_per_ddim_step_bs%d" % per_gpu in out and cal.get("ratio_to_r06_evidence_box", {}).get("gemm_8192_tflops"):
+                # the forward is MFMA-side work: its time on the evidence box's clock
+                out["unet_forward_ms_normalised_to_r06_box"] = round(
+                    out["unet_forward_ms_per_ddim_step_bs%d" % per_gpu] * cal["ratio_to_r06_evidence_box"]["gemm_8192_tflops"], 3)
+        except Exception as e:   # never lose the line over the calibration leg
+            out["box_calibration"] = {"error": str(e)}
     if world == 1 and args.workload == "t2i" and args.batch is None and not args.no_other_workloads:
         # BASELINE configs[2..4] on this GPU, after (and outside) the headline's timed region: the driver only ever runs the
         # default command, this block gives those configurations a driver-run number as well

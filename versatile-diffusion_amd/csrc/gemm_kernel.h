@@ -370,11 +370,13 @@ __device__ __forceinline__ void epi_load_bias(const EpiCtx& e, int N, int col0, 
 }
 // Row statistics of the LayerNorm fold, one 16-byte request per row whatever the source (no branch around the requests):
 // (mean, rstd) fp32 from vd_row_stats_f16 in .x / .y, or -- VD_EPI_LN_SUMS -- the producer's row_sums, two int64 fixed-point
-// sums (ln_sums_decode).  The descriptor ends with the table, so the 8 bytes past the last (mean, rstd) pair read as zeros.
+// sums (ln_sums_decode).
 template <int MI>
 __device__ __forceinline__ void epi_load_lnstats(const float* ln_stats, int M, int z, int row0, uint4* st, bool enable, bool sums, int rows_total) {
     const int rb = sums ? 16 : 8;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ln_stats), 0, (enable && ln_stats != nullptr) ? rows_total * rb : 0, 0x00020000);
+    // (mean, rstd) form: the 16-byte request of the LAST row reaches 8 bytes past the table; the descriptor covers them (+ 8) so the
+    // result does not hang on how the range check treats a request that straddles the end -- the extra dwords are never used
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ln_stats), 0, (enable && ln_stats != nullptr) ? rows_total * rb + (sums ? 0 : 8) : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int row = row0 + i * 32;
@@ -390,12 +392,14 @@ constexpr float LN_SUM_SCALE = 16777216.0f, LN_SQ_SCALE = 65536.0f;
 __device__ __forceinline__ void ln_sums_decode(const uint4 raw, int K, float eps, float& rstd, float& nmr) {
     const long long S1 = (long long)(((unsigned long long)raw.y << 32) | raw.x);
     const long long S2 = (long long)(((unsigned long long)raw.w << 32) | raw.z);
-    const float inv_k = 1.0f / (float)K;
-    const float mean = (float)S1 * (1.0f / LN_SUM_SCALE) * inv_k;
-    float var = (float)S2 * (1.0f / LN_SQ_SCALE) * inv_k - mean * mean;
-    if (var < 0.f) var = 0.f;
-    rstd = rsqrtf(var + eps);
-    nmr = -mean * rstd;
+    // E[x^2] - mean^2 in double: the integers are exact, and in fp32 the one-pass form loses (mean / sigma)^2 * 6e-8 of the variance
+    // for rows whose mean dwarfs their spread (a handful of operations per row and thread)
+    const double inv_k = 1.0 / (double)K;
+    const double mean = (double)S1 * (1.0 / (double)LN_SUM_SCALE) * inv_k;
+    double var = (double)S2 * (1.0 / (double)LN_SQ_SCALE) * inv_k - mean * mean;
+    if (var < 0.0) var = 0.0;
+    rstd = rsqrtf((float)var + eps);
+    nmr = -(float)mean * rstd;
 }
 
 // keep: the stored values are also written back into the tile (the statistics pass behind part 2 reads them there)

@@ -173,7 +173,9 @@ class DDIMSampler(object):
         # ORDERED (storage, version) pairs of every parameter and buffer (an additive checksum would let two parameters
         # that swap storages collide)
         wv = hash(tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers())))
-        key = (id(self.model), wv, str(x.device), tuple(x.shape), x_info["type"], bool(guided), bool(single),
+        # (emb_hoist is part of the key: a step graph captured with the hoisted time embedding reads st["embrow"], one captured
+        # without it computes the embedding inside the step -- replaying either under the other setting would be silently wrong)
+        key = (id(self.model), wv, str(x.device), tuple(x.shape), x_info["type"], bool(guided), bool(single), bool(self.emb_hoist),
                tuple((ci["type"], tuple(ci["c"].shape), float(ci.get("ratio", 1.0))) for ci in c_info_list))
         st = self._static.get(key)
         if st is None:
@@ -269,6 +271,10 @@ class DDIMSampler(object):
             coef.copy_(table[index])
             if embrow is not None:
                 embrow.copy_(emb_tab[i])
+            if graph is not None and st is not None and st.get("graph_embrow", embrow is not None) != (embrow is not None):
+                # the kept graph was captured with / without the hoisted embedding row and this call has it the other way round
+                # (precompute_step_emb started / stopped returning a table): capture again instead of replaying stale conditioning
+                graph = st["graph"] = None
             if (i == 0 and not replay_first) or not self.use_graph:
                 body()
             elif graph is None:
@@ -278,6 +284,7 @@ class DDIMSampler(object):
                 else:
                     if st is not None:
                         st["graph"] = graph
+                        st["graph_embrow"] = embrow is not None
                     graph.replay()
             else:
                 graph.replay()

@@ -138,14 +138,15 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     nb = x.shape[0]
     shared = repeat > 1
     # LayerNorm row statistics accumulated by producer epilogues live in one arena per forward, zeroed by ONE fill
-    arena = data_net.__dict__.get("_vd_rowsum_arena")
-    if arena is None:
-        arena = data_net.__dict__["_vd_rowsum_arena"] = ops.RowSumArena()
+    # (the arena object is per CALL -- two threads running forwards of one net must not hand out overlapping slices -- the module
+    # remembers only how many rows the previous forward took)
+    arena = ops.RowSumArena(data_net.__dict__.get("_vd_rowsum_need", 0))
     arena.begin(x.device)
     try:
         return _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs)
     finally:
         arena.end()
+        data_net.__dict__["_vd_rowsum_need"] = arena.need
 
 
 def _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs):

@@ -134,7 +134,8 @@ def drop_workspaces(stream_id):
 def row_stats(x, C, rows, eps, ldx=None):
     """(mean, rstd) per row of x viewed as [rows][ldx >= C] -> fp32 [rows, 2] (the statistics half of a LayerNorm)."""
     _req(x, "x")
-    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    # (one spare row: the LayerNorm-fold epilogue fetches 16 bytes per row, i.e. 8 bytes past the last (mean, rstd) pair)
+    stats = torch.empty((rows + 1, 2), dtype=torch.float32, device=x.device)[:rows]
     with _Timed("row_stats_kernel", 0.0, rows * C * 2.0 + rows * 8.0):
         _check(lib().vd_row_stats_f16(_ptr(x), _ptr(stats), int(rows), int(C), int(ldx or C), float(eps), _stream()))
     return stats
@@ -404,8 +405,8 @@ class RowSumArena(object):
     """Bump allocator over one zeroed int64 [need, 2] tensor per forward; `need` is what the previous forward of this owner
     took (the first forward, and any request beyond it, falls back to a torch.zeros of its own)."""
 
-    def __init__(self):
-        self.need, self.used, self.buf = 0, 0, None
+    def __init__(self, need=0):
+        self.need, self.used, self.buf = int(need), 0, None
 
     def begin(self, device):
         self.used = 0
