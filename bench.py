@@ -43,8 +43,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_FP16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md chip-level table
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
-TRACE_FILE = "r05_trace_dominant.json"   # tools/trace_dominant.py: rocprofv3 kernel-trace average of the dominant kernel, digest-stamped   # tools/pmc_traffic.py; stamped with the digest of the library it was taken with
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"
+TRACE_FILE = "r06_trace_dominant.json"   # tools/trace_dominant.py: rocprofv3 kernel-trace average of the dominant kernel, digest-stamped   # tools/pmc_traffic.py; stamped with the digest of the library it was taken with
 HBM_PEAK_GBS = 8000.0
 UNET_GF_PER_SAMPLE = 803.3       # 64x64 latent, text ctx L=77
 VAE_DECODE_GF = 2514.5

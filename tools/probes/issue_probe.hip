@@ -59,6 +59,17 @@ __global__ __launch_bounds__(512) void probe(float* out, long long* cyc, int ite
         if constexpr (MODE == 5) { for (int j = 0; j < 8; ++j) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[j]) : "v"(v[j + 8])); }
         if constexpr (MODE == 8) { for (int j = 0; j < 8; ++j) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(v[j + 8]), "v"(v[j + 9])); }
         if constexpr (MODE == 9) { for (int j = 0; j < 16; ++j) asm volatile("v_exp_f16 %0, %0" : "+v"(e[j])); }
+        if constexpr (MODE == 10 || MODE == 11) {
+            // role split between the two waves of a SIMD (512-thread blocks: waves w and w + 4 share one): one issues only the 7
+            // MFMAs, the other only VALU (MODE 10: 16 v_exp_f32, MODE 11: 24 v_fma_f32)
+            if (threadIdx.x < 256) {
+                for (int j = 0; j < 7; ++j) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(j < 3 ? a0 : (j & 1 ? a1 : a2)) : "v"(x), "v"(y));
+            } else if constexpr (MODE == 10) {
+                for (int j = 0; j < 16; ++j) asm volatile("v_exp_f32 %0, %0" : "+v"(e[j]));
+            } else {
+                for (int j = 0; j < 24; ++j) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[j]));
+            }
+        }
     }
     const long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
@@ -103,6 +114,10 @@ int main() {
         run<5>("8 v_cvt_pk_f16_f32", threads, blocks);
         run<8>("8 v_max3_f32 (dependent chain)", threads, blocks);
         run<9>("16 v_exp_f16", threads, blocks);
+        if (threads == 512) {
+            run<10>("waves 0-3: 7 MFMA | waves 4-7: 16 v_exp_f32", threads, blocks);
+            run<11>("waves 0-3: 7 MFMA | waves 4-7: 24 v_fma_f32", threads, blocks);
+        }
     }
     return 0;
 }

@@ -10,18 +10,22 @@ from vd_hip import ops
 dev = torch.device("cuda:0")
 net = bench.build_model(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-MODE = sys.argv[2] if len(sys.argv) > 2 else "t2i"   # "dual": BASELINE configs[3] per-GPU share (text 77 + image 257, mixed 0.5 / 0.5)
-x = torch.randn(2 * B, 4, 64, 64, device=dev, dtype=torch.float16)
+MODE = sys.argv[2] if len(sys.argv) > 2 else "t2i"   # per-GPU shares of BASELINE configs[1..4]: t2i | i2v (image context 257) | dual
+#   (text 77 + image 257, mixed 0.5 / 0.5) | triple (96x96 latents: text 77 + two masked images 257 + 257 -> 514)
+SIDE = 96 if MODE == "triple" else 64
+x = torch.randn(2 * B, 4, SIDE, SIDE, device=dev, dtype=torch.float16)
 t = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
 c = torch.randn(2 * B, 77, 768, device=dev, dtype=torch.float16) * 0.5
-ci = torch.randn(2 * B, 257, 768, device=dev, dtype=torch.float16) * 0.5
+ci = torch.randn(2 * B, 514 if MODE == "triple" else 257, 768, device=dev, dtype=torch.float16) * 0.5
 _kv = [{}, {}]
 
 
 def forward():
-    if MODE == "dual":
+    if MODE in ("dual", "triple"):
         return net.apply_model_multicontext({"type": "image", "x": x}, t, [{"type": "text", "c": c, "ratio": 0.5, "kv_cache": _kv[0]},
                                                                            {"type": "image", "c": ci, "ratio": 0.5, "kv_cache": _kv[1]}])
+    if MODE == "i2v":
+        return net.apply_model({"type": "image", "x": x}, t, {"type": "image", "c": ci, "kv_cache": _kv[1]})
     return net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
 
 
