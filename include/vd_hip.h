@@ -20,8 +20,12 @@
  *     thread).  Process-wide state is limited to the optional tuned launch table (vd_gemm_tune_*,
  *     mutex-protected), the developer tile override (atomic), per-device kernel attributes
  *     (atomic bit mask, idempotent) and development switches read once from the environment
- *     (VD_GEMM_VARIANT / VD_GEMM_NT / VD_GEMM_TILE: function-local statics, initialised under the
+ *     (VD_GEMM_TILE / VD_CONV_HALO / VD_ATTN_PIPE: function-local statics, initialised under the
  *     C++11 guarantee).  Scratch (workspaces, split-K counters) is caller-owned, one set per stream.
+ *
+ * ABI 8 (round 6) REMOVED entry points and options that had lost every measurement (vd_conv3x3_wreg_*,
+ * vd_gemm_groupnorm_ok, VD_EPI_GROUPNORM / VD_EPI_GN_SILU: rejected, VdGemmDesc.gn_*: reserved); nothing
+ * was added, and no struct layout changed.
  */
 #ifndef VD_HIP_H
 #define VD_HIP_H
