@@ -21,7 +21,7 @@ def timeit(fn, iters=20):
 
 
 def attn_cases():
-    for (B, H, Nq, Nk, D) in [(8, 8, 4096, 4096, 40), (8, 8, 1024, 1024, 80), (8, 8, 256, 256, 160), (8, 8, 4096, 77, 40),
+    for (B, H, Nq, Nk, D) in [(8, 8, 4096, 4096, 40), (8, 8, 9216, 9216, 40), (4, 8, 4096, 4096, 40), (16, 8, 4096, 4096, 40), (8, 8, 1024, 1024, 80), (8, 8, 256, 256, 160), (8, 8, 4096, 77, 40),
                               (8, 8, 1024, 77, 80), (8, 12, 77, 77, 64), (8, 16, 257, 257, 64)]:
         C = H * D
         qkv = torch.randn(B, Nq, 3 * C, device=dev, dtype=torch.float16)
