@@ -260,7 +260,7 @@ def graph_step_ms(net, sampler, wl, batch, steps, device, reps=20):
 
 # reference values of box_calibration on the round-6 evidence box (profiles/r06_bench.json): the `ratio` fields of a later line say
 # how fast THAT box is against it -- boxes of this pool spread +-4 %, more than a round's gain
-CAL_REF = {"gemm_8192_tflops": None, "copy_256mb_tbps": None}
+CAL_REF = {"gemm_8192_tflops": 776.0, "copy_256mb_tbps": 5.318}
 
 
 def box_calibration(device):
