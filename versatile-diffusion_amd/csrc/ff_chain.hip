@@ -151,21 +151,29 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
     constexpr int CH = FC_C / 8;                       // 40 segments per row
     constexpr int PER = FC_BM * CH / 512;              // 10 per thread
     // 16-byte row segments of the tile: tile + add (global) -> stored to dst (STORE) and / or written back into the tile (KEEP).
-    // The add operands of all of a thread's segments are requested back to back, in front of the tile reads.
-    auto segments = [&](auto store_tag, auto keep_tag, const f16* add, f16* dst, bool nt) {
-        constexpr bool STORE = decltype(store_tag)::value, KEEP = decltype(keep_tag)::value;
+    // seg_request issues the loads of the add operand for all of a thread's segments back to back; seg_finish consumes them.  Round 6: the
+    // two projections request their residual IN FRONT of the K loop (the ten registers wait across it), so its round trip -- ~2 us with the
+    // whole chip asking at once -- no longer sits between the projection and the next stage.
+    struct SegAdd { uint4 v[PER]; };
+    auto seg_request = [&](const f16* add) {
         // (the thread index is laundered: hipcc would otherwise keep the ten 64-bit segment addresses of every call alive across
         // the feed-forward loop -- 60-80 spilled registers -- instead of recomputing them)
         int tl = tid;
         asm volatile("" : "+v"(tl));
-        uint4 ad[PER];
+        SegAdd a;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int sgm = tl + k * 512;
             const int r = sgm / CH, cc = (sgm % CH) * 8;
             const int grow = m0 + r < p.M ? m0 + r : p.M - 1;
-            ad[k] = *reinterpret_cast<const uint4*>(add + (size_t)grow * FC_C + cc);
+            a.v[k] = *reinterpret_cast<const uint4*>(add + (size_t)grow * FC_C + cc);
         }
+        return a;
+    };
+    auto seg_finish = [&](auto store_tag, auto keep_tag, const SegAdd& ad, f16* dst, bool nt) {
+        constexpr bool STORE = decltype(store_tag)::value, KEEP = decltype(keep_tag)::value;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int sgm = tl + k * 512;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
             const int grow = m0 + r;
             U4H8 t, a, o;
             t.u = *reinterpret_cast<const uint4*>(cs + r * FC_CS_LD + cc);
-            a.u = ad[k];
+            a.u = ad.v[k];
 #pragma unroll
             for (int q = 0; q < 8; ++q) o.e[q] = (f16)((float)t.e[q] + (float)a.e[q]);
             if constexpr (STORE) {
@@ -185,6 +193,10 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
             }
             if constexpr (KEEP) *reinterpret_cast<uint4*>(cs + r * FC_CS_LD + cc) = o.u;
         }
+    };
+    auto segments = [&](auto store_tag, auto keep_tag, const f16* add, f16* dst, bool nt) {
+        const SegAdd ad = seg_request(add);
+        seg_finish(store_tag, keep_tag, ad, dst, nt);
     };
     constexpr std::true_type YES{};
     constexpr std::false_type NO{};
@@ -208,11 +220,12 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
         zero_acc2();
         wait_vm<0>();
         __syncthreads();
+        const SegAdd x0seg = seg_request(p.x);   // the residual of this projection: in flight across its K loop
         proj_stage(p.wo);
         acc_to_tile(p.bo, 1.0f);
         wait_vm<0>();
         __syncthreads();
-        segments(YES, YES, p.x, p.x1, false);
+        seg_finish(YES, YES, x0seg, p.x1, false);
         wait_vm<0>();
         __syncthreads();
 #pragma unroll
@@ -413,12 +426,13 @@ __global__ __launch_bounds__(512, 2) void ff_chain_kernel(const FCArgs p) {
         zero_acc2();
         wait_vm<0>();
         __syncthreads();
+        const SegAdd rseg = seg_request(p.r);    // the residual of the last projection: in flight across its K loop
         proj_stage(p.wp);
         acc_to_tile(p.bp, p.alpha);
         wait_vm<0>();
         __syncthreads();
         const bool stats = p.out_stats != nullptr;
-        segments(YES, YES, p.r, p.y, p.nt_store != 0);
+        seg_finish(YES, YES, rseg, p.y, p.nt_store != 0);
         if (stats) {
             __syncthreads();
             const int left = (p.M - m0) / FC_BM;
