@@ -206,6 +206,38 @@ def test_state_dict_layout_matches_reference():
     assert net.to("cpu") is None and net.device == "cpu"  # reference quirk: .to() returns None
 
 
+def test_half_batch_fork_region_of_the_unet_walk():
+    """vd._fork_region: the 16x16 / 8x8 levels and the middle block of openai_unet_2d_v1 (from the Downsample that enters the 16x16
+    level up to the Upsample that leaves it), skip tensors balanced inside; nothing for the 0-D net or a threshold no level meets."""
+    from lib.cfg_helper import model_cfg_bank
+    from lib.model_zoo import get_model
+    from lib.model_zoo import vd
+    from lib.model_zoo.openaimodel import Downsample, Upsample
+    with torch.device("meta"):
+        net = get_model()(model_cfg_bank()("openai_unet_2d_v1"), verbose=False)
+    d_iter, c_iter, steps = iter(enumerate(net.data_blocks)), iter(net.context_blocks), []
+    for lt in list(net.i_order) + list(net.m_order) + list(net.o_order):
+        if lt == "d":
+            di, blk = next(d_iter)
+            steps.append(("d", di, blk))
+        elif lt == "c":
+            steps.append(("c", [next(c_iter)], [None], [1.0]))
+        else:
+            steps.append(("save",) if lt == "save_hidden_feature" else ("load",))
+    a, b = vd._fork_region(steps, 64 * 64, 256)
+    assert isinstance(steps[a][2][0], Downsample) and isinstance(steps[b][2][0], Upsample)
+    downs = [i for i, st in enumerate(steps) if st[0] == "d" and isinstance(st[2][0], Downsample)]
+    ups = [i for i, st in enumerate(steps) if st[0] == "d" and isinstance(st[2][0], Upsample)]
+    assert a == downs[1] and b == ups[1]          # 64 -> 32 -> [16 -> 8 ... 8 -> 16] -> 32 -> 64
+    inside = steps[a:b]
+    assert sum(st[0] == "save" for st in inside) == sum(st[0] == "load" for st in inside) == 6
+    assert sum(st[0] == "c" for st in inside) == 6   # 2 + 3 transformer blocks of the 16x16 level, the middle block's, none at 8x8
+    a2, b2 = vd._fork_region(steps, 64 * 64, 1024)
+    assert a2 == downs[0] and b2 == ups[2]
+    assert vd._fork_region(steps, 64 * 64, 16) is None        # no level that small
+    assert vd._fork_region(steps, 16 * 16, 256) is None       # a 16x16 latent never leaves the range again: no region
+
+
 def test_full_unet_structure():
     """Block inventory of openai_unet_2d_v1 without allocating it."""
     from lib.cfg_helper import model_cfg_bank

@@ -246,6 +246,40 @@ def test_full_unet_forward_vs_oracle(full, dev):
     assert rel_l2(e2, ref2) < FWD_TOL
 
 
+def test_half_batch_branches_match_the_unforked_forward(full, dev, monkeypatch):
+    """vd.BATCH_FORK: the 16x16 / 8x8 levels as two forked half-batch branches (default for batches of >= 16 samples with one
+    context type) against the same forward without the fork -- same kernels on the same values per sample, other split-K
+    factors and statistics partials for the smaller batch, so agreement to the fp16 noise of a forward (the oracle tests put that
+    at FWD_TOL), eager and inside a captured graph; a multi-context forward is not forked (its context types are)."""
+    from lib.model_zoo import vd
+    net, _ = full
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn((4, 4, 64, 64), generator=g)).half().to(dev)   # (64x64: the geometry whose forward is bit-reproducible run to run)
+    c = (torch.randn((4, 77, 768), generator=g) * 0.5).half().to(dev)
+    t = torch.tensor([741, 741, 301, 301], device=dev)
+    fwd = lambda: net.apply_model({"type": "image", "x": x}, t, {"type": "text", "c": c})
+    monkeypatch.setattr(vd, "BATCH_FORK", "0")
+    ref = fwd().float()
+    monkeypatch.setattr(vd, "BATCH_FORK", "1")
+    out = fwd().float()
+    assert rel_l2(out, ref) < FWD_TOL and not torch.equal(out, ref)   # (the fork did run: other split factors -> other roundings)
+    again = fwd().float()
+    assert torch.equal(out, again)                                    # run-to-run identical
+    # captured and replayed (the sampler's step graph): the side branch must join the capture
+    fwd(); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cap = fwd()
+    gr.replay(); torch.cuda.synchronize()
+    assert rel_l2(cap.float(), ref) < FWD_TOL
+    c2 = (torch.randn((4, 257, 768), generator=g) * 0.5).half().to(dev)
+    multi = lambda: net.apply_model_multicontext({"type": "image", "x": x}, t, [
+        {"type": "text", "c": c, "ratio": 0.5}, {"type": "image", "c": c2, "ratio": 0.5}]).float()
+    m1 = multi()
+    monkeypatch.setattr(vd, "BATCH_FORK", "0")
+    assert torch.equal(m1, multi())
+
+
 def test_bench_shape_forward_vs_oracle(full, dev):
     """The exact shape bench.py times (BASELINE configs[1]): CFG batch 8, 64x64 latent, L = 77 -- so the tile / split
     choices, the 128x320 tile of the 64x64 level and the attention kernel at N = 4096 are checked at full width."""

@@ -38,14 +38,23 @@ class String_Reg_Buffer(nn.Module):
 
 
 CTX_FORK = os.environ.get("VD_CTX_FORK", "1") != "0"   # development switch: 0 = the context types of a block one after the other
+# Round 6: the low-resolution levels of the UNet (rows per sample <= VD_BATCH_FORK_HW, default 256 = the 16x16 and 8x8 levels and the
+# middle block) as TWO forked branches of half the batch each.  Measured (profiles/HISTORY.md R6.8): image variation at CFG batch 16
+# +1.6 .. +2.5 % images/s (each half is the CFG-batch-8 problem the planner's rules were measured on, and the halves' latency-bound
+# launches fill each other's gaps); text-to-image at CFG batch 8 -4 % (halves of 4 samples: split-K convolutions that each fill
+# the chip cannot run side by side).  So: "auto" = batches of >= VD_BATCH_FORK_MIN (16) samples with ONE context type (the context
+# types of a multi-context stage are forked already); 0 = never, 1 = every even batch with one context type.
+BATCH_FORK = os.environ.get("VD_BATCH_FORK", "auto")
+BATCH_FORK_HW = int(os.environ.get("VD_BATCH_FORK_HW", "256"))
+BATCH_FORK_MIN = int(os.environ.get("VD_BATCH_FORK_MIN", "16"))
 _SIDE = {}
 
 
-def _side_streams(device, n):
+def _side_streams(device, n, kind="ctx"):
     """Side streams of the forked context-type branches, one set per device for the whole process: the eager warm-up step and
     the captured step use the same streams, so the per-stream workspaces of vd_hip.ops (keyed by stream) are allocated once,
     outside any capture."""
-    lst = _SIDE.setdefault(device.index, [])
+    lst = _SIDE.setdefault((kind, device.index), [])
     while len(lst) < n:
         lst.append(torch.cuda.Stream(device=device))
     return lst[:n]
@@ -71,7 +80,24 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     c_iters = [iter(spec[0]) for spec in ctx_specs]
     ratios = np.array([float(spec[2]) for spec in ctx_specs], dtype=np.float64)
     ratios = ratios / ratios.sum()
-    hs = []
+
+    # the walk, resolved to modules once: ("d", index, block) / ("c", modules, specs, ratios) / ("save",) / ("load",)
+    steps = []
+    for ltype in list(data_net.i_order) + list(data_net.m_order) + list(data_net.o_order):
+        if ltype == "d":
+            di, blk = next(d_iter)
+            steps.append(("d", di, blk))
+        elif ltype == "c":
+            modules = [next(it) for it in c_iters]
+            if mixing_type == "layer":
+                pick = int(npr.choice(len(modules), p=ratios))
+                steps.append(("c", [modules[pick]], [ctx_specs[pick]], [1.0]))
+            else:
+                steps.append(("c", modules, list(ctx_specs), ratios))
+        elif ltype == "save_hidden_feature":
+            steps.append(("save",))
+        elif ltype == "load_hidden_feature":
+            steps.append(("load",))
 
     def context_kv(module, spec):
         _, c, _, cache = spec
@@ -88,15 +114,13 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
                 stale.discard(id(module))
         return kv
 
-    def run_context(h):
-        modules = [next(it) for it in c_iters]
-        if mixing_type == "layer":
-            pick = int(npr.choice(len(modules), p=ratios))
-            modules, specs, rs = [modules[pick]], [ctx_specs[pick]], [1.0]
-        else:
-            specs, rs = ctx_specs, ratios
+    def run_context(h, modules, specs, rs, sl=None):
+        """sl = (b0, b1): h holds samples b0 .. b1 - 1 of the batch (a half-batch branch): contexts and K/V are sliced alike."""
         single = len(modules) == 1
         kvs = [context_kv(m, sp) for m, sp in zip(modules, specs)]
+        if sl is not None:
+            kvs = [None if kv is None else kv[sl[0]:sl[1]] for kv in kvs]
+            specs = [(sp[0], None if sp[1] is None else sp[1][sl[0]:sl[1]]) + tuple(sp[2:]) for sp in specs]
         # h_out = sum_i r_i * ST_i(h) = sum_i r_i * proj_i + h   (sum r_i = 1): chained through the epilogue of each type's LAST
         # launch (alpha = r_i, res = the previous type's output).  Everything in front of that launch depends on h only, so the
         # types run as forked branches (side streams; inside the sampler's HIP graph: parallel branches): at the per-GPU batch of
@@ -143,40 +167,106 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     arena = ops.RowSumArena(data_net.__dict__.get("_vd_rowsum_need", 0))
     arena.begin(x.device)
     try:
-        return _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs)
+        return _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, lambda ms, sps: [context_kv(m, sp) for m, sp in zip(ms, sps)],
+                              h, nb, shared, repeat)
     finally:
         arena.end()
         data_net.__dict__["_vd_rowsum_need"] = arena.need
 
 
-def _run_unet_body(data_net, d_iter, emb_outs, emb_rows, emb_silu, run_context, h, nb, shared, repeat, hs):
-    for ltype in data_net.i_order + data_net.m_order:
-        if ltype == "d":
-            di, blk = next(d_iter)
-            eo = emb_outs.get(di)
-            if shared:
-                h = blk(h, None if emb_silu is None else emb_silu[:nb], None, emb_out=None if eo is None else eo[:nb],
-                        emb_bias=emb_rows.get(di))
-            else:
-                h = blk(h, emb_silu, None, emb_out=eo, emb_bias=emb_rows.get(di))
-        elif ltype == "c":
-            if shared:  # the replicas diverge here
-                rep = lambda t: ops.repeat_batch(t, repeat)   # per-channel statistics of the tensors travel along
-                h, hs, shared = rep(h), [rep(t) for t in hs], False
-            h = run_context(h)
-        elif ltype == "save_hidden_feature":
-            hs.append(h)
-    assert not shared, "run_unet(repeat > 1) needs a context block in the input or middle stage"
-    skip = None
-    for ltype in data_net.o_order:
-        if ltype == "load_hidden_feature":
-            skip = hs.pop()
-        elif ltype == "d":
-            di, blk = next(d_iter)
-            h = blk(h, emb_silu, None, skip=skip, emb_out=emb_outs.get(di), emb_bias=emb_rows.get(di))
-            skip = None
-        elif ltype == "c":
-            h = run_context(h)
+def _fork_region(steps, hw0, thr):
+    """[a, b) of `steps`: from the Downsample that brings the rows per sample to <= thr up to (not including) the Upsample that
+    leaves that range again, or None.  The region must keep its skip tensors to itself (as many loads as saves, never below)."""
+    from .openaimodel import Downsample, Upsample
+    hw, a, b = hw0, None, None
+    for i, st in enumerate(steps):
+        if st[0] != "d":
+            continue
+        layers = list(st[2]) if isinstance(st[2], (nn.Sequential, list, tuple)) else [st[2]]
+        if any(isinstance(l, Downsample) for l in layers):
+            hw //= 4
+            if a is None and hw <= thr:
+                a = i
+        elif any(isinstance(l, Upsample) for l in layers):
+            if a is not None and b is None and hw <= thr and hw * 4 > thr:
+                b = i
+            hw *= 4
+    if a is None or b is None or b <= a:
+        return None
+    depth = 0
+    for st in steps[a:b]:
+        depth += 1 if st[0] == "save" else (-1 if st[0] == "load" else 0)
+        if depth < 0:
+            return None
+    return (a, b) if depth == 0 and any(st[0] == "c" for st in steps[a:b]) else None
+
+
+def _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, prepare_context, h, nb, shared, repeat):
+    state = {"shared": shared}
+
+    def walk(lo, hi, h, hs, sl=None):
+        """steps[lo:hi] on h; sl = (b0, b1): h is that slice of the batch (per-sample inputs are sliced alike)."""
+        rows = (lambda t: t) if sl is None else (lambda t: None if t is None else t[sl[0]:sl[1]])
+        skip = None
+        for st in steps[lo:hi]:
+            if st[0] == "d":
+                di, blk = st[1], st[2]
+                eo = emb_outs.get(di)
+                if state["shared"]:
+                    h = blk(h, None if emb_silu is None else emb_silu[:nb], None, emb_out=None if eo is None else eo[:nb],
+                            emb_bias=emb_rows.get(di))
+                else:
+                    h = blk(h, rows(emb_silu), None, skip=skip, emb_out=rows(eo), emb_bias=emb_rows.get(di))
+                skip = None
+            elif st[0] == "c":
+                if state["shared"]:  # the replicas diverge here
+                    rep = lambda t: ops.repeat_batch(t, repeat)   # per-channel statistics of the tensors travel along
+                    h, hs[:] = rep(h), [rep(t) for t in hs]
+                    state["shared"] = False
+                h = run_context(h, st[1], st[2], st[3], sl)
+            elif st[0] == "save":
+                hs.append(h)
+            elif st[0] == "load":
+                skip = hs.pop()
+        assert skip is None
+        return h
+
+    hs = []
+    region = None
+    if BATCH_FORK != "0" and h.is_cuda and h.dim() == 4 and all(len(st[1]) == 1 for st in steps if st[0] == "c"):
+        region = _fork_region(steps, h.shape[-2] * h.shape[-1], BATCH_FORK_HW)
+    if region is None:
+        h = walk(0, len(steps), h, hs)
+    else:
+        a, b = region
+        h = walk(0, a, h, hs)
+        B = h.shape[0]
+        if state["shared"] or B < 2 or B % 2 or (BATCH_FORK != "1" and B < BATCH_FORK_MIN):
+            h = walk(a, len(steps), h, hs)
+        else:
+            # two half-batch branches: samples 0 .. B/2 - 1 on the current stream, the rest on a side stream (inside the sampler's
+            # HIP graph: parallel branches).  Batch slices of channels-last tensors are contiguous views; the region's skip tensors
+            # stay inside it; nothing in it is consumed with producer statistics outside (the Upsample conv behind it takes none).
+            # (cached context K/V of the region's blocks are projected -- or refreshed -- HERE, in front of the fork: a branch that
+            # projected them on first use would hand the other branch a tensor its stream has not waited for)
+            for st in steps[a:b]:
+                if st[0] == "c":
+                    prepare_context(st[1], st[2])
+            main = torch.cuda.current_stream()
+            side = _side_streams(h.device, 1, kind="batch")[0]
+            fork = torch.cuda.Event()
+            fork.record(main)
+            h0 = walk(a, b, h[:B // 2], [], (0, B // 2))
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                h1 = walk(a, b, h[B // 2:], [], (B // 2, B))
+                done = torch.cuda.Event()
+                done.record(side)
+            h1.record_stream(main)
+            main.wait_event(done)
+            h = torch.cat([h0, h1], 0)
+            h = walk(b, len(steps), h, hs)
+    assert not state["shared"], "run_unet(repeat > 1) needs a context block in the input or middle stage"
     return h if h.dim() == 2 else ops.nhwc_to_nchw(h)   # 0-D (text-latent) data flow ends in [B, D]
 
 
