@@ -168,7 +168,7 @@ def run_unet(data_net, ctx_specs, x, emb_silu, mixing_type="attention", repeat=1
     arena.begin(x.device)
     try:
         return _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, lambda ms, sps: [context_kv(m, sp) for m, sp in zip(ms, sps)],
-                              h, nb, shared, repeat)
+                              h, nb, shared, repeat, data_net.__dict__.setdefault("_vd_fork_warm", set()))
     finally:
         arena.end()
         data_net.__dict__["_vd_rowsum_need"] = arena.need
@@ -201,7 +201,7 @@ def _fork_region(steps, hw0, thr):
     return (a, b) if depth == 0 and any(st[0] == "c" for st in steps[a:b]) else None
 
 
-def _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, prepare_context, h, nb, shared, repeat):
+def _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, prepare_context, h, nb, shared, repeat, warm):
     state = {"shared": shared}
 
     def walk(lo, hi, h, hs, sl=None):
@@ -252,11 +252,20 @@ def _run_unet_body(steps, emb_outs, emb_rows, emb_silu, run_context, prepare_con
             for st in steps[a:b]:
                 if st[0] == "c":
                     prepare_context(st[1], st[2])
+            # (the FIRST forward of a geometry orders the side branch behind the whole main branch: weight packs are built lazily at
+            # first use, and a pack built by one branch would reach the other unsynchronised; both halves have the same shapes, so
+            # the main branch builds every pack the side branch needs)
+            key = (B,) + tuple(h.shape[1:]) + tuple(id(st[1][0]) for st in steps[a:b] if st[0] == "c")[:1]
+            first = key not in warm
+            warm.add(key)
             main = torch.cuda.current_stream()
             side = _side_streams(h.device, 1, kind="batch")[0]
             fork = torch.cuda.Event()
-            fork.record(main)
+            if not first:
+                fork.record(main)
             h0 = walk(a, b, h[:B // 2], [], (0, B // 2))
+            if first:
+                fork.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 h1 = walk(a, b, h[B // 2:], [], (B // 2, B))
