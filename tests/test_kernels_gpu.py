@@ -738,6 +738,23 @@ def test_groupnorm(ops, dev, B, HW, c0, c1, silu, eps):
     assert rel_l2(out, ref) < 2e-3
 
 
+def test_single_launch_groupnorms_are_bit_identical_run_to_run(ops, dev):
+    """gn_slab_kernel / gn0d_kernel fold their per-thread partials in LDS as 64-bit integers at a block-wide power-of-two scale (round 6;
+    float atomics before: arrival order, so two runs could differ in the last bits) -- 30 runs each must agree exactly, also for
+    tiny and for large-mean inputs (the scale follows the block's largest partial)."""
+    for scale, shift in ((2.0, 0.5), (1e-3, 0.0), (0.05, 300.0)):
+        x = rnd((4, 16, 1280), dev, scale, 50) + shift       # the 4x4 level of a 32x32-latent forward: slab kernel
+        gamma, beta = rnd((1280,), dev, 0.5, 51) + 1.0, rnd((1280,), dev, 0.5, 52)
+        outs = [ops.groupnorm_silu(x, gamma, beta, groups=32, eps=1e-5, silu=True) for _ in range(30)]
+        assert all(torch.equal(o, outs[0]) for o in outs[1:])
+        ref = F.silu(F.group_norm(x.float().permute(0, 2, 1), 32, gamma.float(), beta.float(), 1e-5).permute(0, 2, 1))
+        assert rel_l2(outs[0], ref) < (2e-3 if shift < 100 else 2e-2)   # (fp16 input at mean 300: the input's own rounding dominates)
+        x0 = rnd((3, 4, 1280), dev, scale, 53) + shift
+        g2, b2 = rnd((4, 1280), dev, 0.5, 54) + 1.0, rnd((4, 1280), dev, 0.5, 55)
+        outs = [ops.groupnorm0d_silu(x0, g2, b2, groups=32, eps=1e-5, silu=True) for _ in range(30)]
+        assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
 @pytest.mark.parametrize("HW,C", [(4096, 320), (256, 1280), (64, 1280)])
 def test_groupnorm_large_mean_small_spread(ops, dev, HW, C):
     """|mean| >> sigma with eps = 1e-6 (VAE / SpatialTransformer norms): a plain E[x^2] - mean^2 in fp32 loses the

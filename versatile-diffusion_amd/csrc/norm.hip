@@ -43,6 +43,22 @@ __device__ __forceinline__ const f16* gn_src(const f16* x0, int c0, const f16* x
     return (ch < c0) ? (x0 + row * c0 + ch) : (x1 + row * c1 + (ch - c0));
 }
 
+// Order-independent accumulation in LDS (round 6).  Float atomics add in arrival order, so two runs of one launch could differ in
+// the last bits (found on the 4x4 level of a 32x32-latent forward and in the 0-D flow; the 64x64 / 96x96 geometries never take these
+// kernels' atomics).  The single-launch kernels below add their per-thread partials as 64-bit INTEGERS instead (integer adds
+// commute): a first sweep takes the block's largest |partial| of each quantity with an integer max on the float bits (exact, order-free),
+// which fixes a power-of-two scale 2^se with max * 2^se < 2^39 -- 2^13 contributions stay below 2^52, and every partial keeps its
+// fp32 mantissa down to 2^-39 of the largest one.
+__device__ __forceinline__ int fx_scale_exp(unsigned maxbits) {
+    const int e = (int)((maxbits >> 23) & 255) - 127;   // floor(log2(max)); max == 0: -127
+    const int se = 38 - e;
+    return se > 120 ? 120 : se;
+}
+__device__ __forceinline__ void fx_add(long long* p, float v, int se) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(ldexpf(v, se)));
+}
+__device__ __forceinline__ float fx_get(long long v, int se) { return (float)ldexp((double)v, -se); }
+
 // One-pass variance with a per-group SHIFT: sums run over (x - k_g), k_g = the group's first sample (row 0, first channel
 // of the group).  Any sample lies within a few sigma of the mean, so sum((x-k)^2)/n - (sum(x-k)/n)^2 no longer cancels
 // catastrophically when |mean| >> sigma (a plain E[x^2] - mean^2 in fp32 collapses to var = 0 there, which matters with
@@ -235,12 +251,14 @@ template <int NITEM>
 __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
                                                       const f16* beta, f16* y, int HW, int C, int cg, int slab_chunks,
                                                       int apply_silu, float inv_count, float eps) {
-    __shared__ float ls[16 * 2];  // <= 16 groups per slab
+    __shared__ long long ls[16 * 2];  // <= 16 groups per slab: fixed-point (sum, sum of squares), see fx_add
+    __shared__ unsigned mx[2];
     __shared__ float stat[16 * 2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int ch0 = blockIdx.x * slab_chunks * 8;  // first channel of the slab
     const int ngrp = slab_chunks * 8 / cg;
-    if (tid < 32) ls[tid] = 0.f;
+    if (tid < 32) ls[tid] = 0;
+    if (tid < 2) mx[tid] = 0u;
     __syncthreads();
     // a thread keeps ONE 8-channel chunk of the slab and walks the rows: its per-channel sums stay in registers and
     // reach LDS once (walking items linearly instead costs an LDS atomic pair per item on a handful of addresses)
@@ -249,6 +267,26 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
     const bool active = rl < rp;
     const int ch = ch0 + ck * 8;
     U4H8 t[NITEM];
+    float sm[8], sq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[i] = sq[i] = 0.f;
+    // the (up to 8) channels of the chunk folded into their groups, one (sum, sum of squares) pair per run of one group
+    auto runs = [&](auto&& emit) {
+        int gcur = (ck * 8) / cg;
+        float as = 0.f, aq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gi = (ck * 8 + i) / cg;
+            if (gi != gcur) {
+                emit(gcur, as, aq);
+                as = aq = 0.f;
+                gcur = gi;
+            }
+            as += sm[i];
+            aq += sq[i];
+        }
+        emit(gcur, as, aq);
+    };
     if (active) {
         // all loads unconditional and back to back; rows past HW re-read the last row and are weighted 0
         float wgt[NITEM];
@@ -258,9 +296,7 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
             wgt[u] = r < HW ? 1.f : 0.f;
             t[u].u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * HW + (r < HW ? r : HW - 1), ch));
         }
-        float sm[8], sq[8], kk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sm[i] = sq[i] = 0.f;
+        float kk[8];
         gn_shift8(kk, x0, c0, x1, c1, (size_t)b * HW, ch, cg);
 #pragma unroll
         for (int u = 0; u < NITEM; ++u)
@@ -270,27 +306,18 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
                 sm[i] += v;
                 sq[i] += v * v;
             }
-        int gcur = (ck * 8) / cg;
-        float as = 0.f, aq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int gi = (ck * 8 + i) / cg;
-            if (gi != gcur) {
-                atomicAdd(&ls[gcur * 2], as);
-                atomicAdd(&ls[gcur * 2 + 1], aq);
-                as = aq = 0.f;
-                gcur = gi;
-            }
-            as += sm[i];
-            aq += sq[i];
-        }
-        atomicAdd(&ls[gcur * 2], as);
-        atomicAdd(&ls[gcur * 2 + 1], aq);
+        float ma = 0.f, mq = 0.f;
+        runs([&](int, float as, float aq) { ma = fmaxf(ma, fabsf(as)); mq = fmaxf(mq, aq); });
+        atomicMax(&mx[0], __float_as_uint(ma));
+        atomicMax(&mx[1], __float_as_uint(mq));
     }
     __syncthreads();
+    const int ses = fx_scale_exp(mx[0]), seq = fx_scale_exp(mx[1]);
+    if (active) runs([&](int g, float as, float aq) { fx_add(&ls[g * 2], as, ses); fx_add(&ls[g * 2 + 1], aq, seq); });
+    __syncthreads();
     if (tid < ngrp) {
-        const float ms = ls[tid * 2] * inv_count;
-        float var = ls[tid * 2 + 1] * inv_count - ms * ms;
+        const float ms = fx_get(ls[tid * 2], ses) * inv_count;
+        float var = fx_get(ls[tid * 2 + 1], seq) * inv_count - ms * ms;
         if (var < 0.f) var = 0.f;
         stat[tid * 2] = ms + gn_shift(x0, c0, x1, c1, (size_t)b * HW, ch0 / cg + tid, cg);
         stat[tid * 2 + 1] = rsqrtf(var + eps);
@@ -330,40 +357,52 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const f16* x0, int c0, con
 // sample is <= 10240 elements.
 __global__ __launch_bounds__(256) void gn0d_kernel(const f16* x0, int c0, const f16* x1, int c1, const f16* gamma,
                                                    const f16* beta, f16* y, int S, int groups, int apply_silu, float eps) {
-    __shared__ float ls[64 * 2];
+    __shared__ long long ls[64 * 2];   // fixed-point (sum, sum of squares) per group, see fx_add
+    __shared__ unsigned mx[2];
     __shared__ float stat[64 * 2];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int C = c0 + c1, C8 = C / 8, cg = C / groups;
-    if (tid < groups * 2) ls[tid] = 0.f;
+    if (tid < groups * 2) ls[tid] = 0;
+    if (tid < 2) mx[tid] = 0u;
     __syncthreads();
     const int nchunk = S * C8;
-    for (int i = tid; i < nchunk; i += 256) {
-        const int s = i / C8, cc = i - s * C8;
-        U4H8 t;
-        t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * S + s, cc * 8));
-        int gcur = (cc * 8) / cg;
-        float as = 0.f, aq = 0.f;
+    // every 8-channel chunk of the sample folded into its groups: emit(group, sum, sum of squares) per run of one group
+    auto sweep = [&](auto&& emit) {
+        for (int i = tid; i < nchunk; i += 256) {
+            const int s = i / C8, cc = i - s * C8;
+            U4H8 t;
+            t.u = *reinterpret_cast<const uint4*>(gn_src(x0, c0, x1, c1, (size_t)b * S + s, cc * 8));
+            int gcur = (cc * 8) / cg;
+            float as = 0.f, aq = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int gi = (cc * 8 + k) / cg;
-            if (gi != gcur) {
-                atomicAdd(&ls[gcur * 2], as);
-                atomicAdd(&ls[gcur * 2 + 1], aq);
-                as = aq = 0.f;
-                gcur = gi;
+            for (int k = 0; k < 8; ++k) {
+                const int gi = (cc * 8 + k) / cg;
+                if (gi != gcur) {
+                    emit(gcur, as, aq);
+                    as = aq = 0.f;
+                    gcur = gi;
+                }
+                const float v = (float)t.e[k] - gn_shift(x0, c0, x1, c1, (size_t)b * S, gi, cg);
+                as += v;
+                aq += v * v;
             }
-            const float v = (float)t.e[k] - gn_shift(x0, c0, x1, c1, (size_t)b * S, gi, cg);
-            as += v;
-            aq += v * v;
+            emit(gcur, as, aq);
         }
-        atomicAdd(&ls[gcur * 2], as);
-        atomicAdd(&ls[gcur * 2 + 1], aq);
+    };
+    {
+        float ma = 0.f, mq = 0.f;
+        sweep([&](int, float as, float aq) { ma = fmaxf(ma, fabsf(as)); mq = fmaxf(mq, aq); });
+        atomicMax(&mx[0], __float_as_uint(ma));
+        atomicMax(&mx[1], __float_as_uint(mq));
     }
+    __syncthreads();
+    const int ses = fx_scale_exp(mx[0]), seq = fx_scale_exp(mx[1]);
+    sweep([&](int g, float as, float aq) { fx_add(&ls[g * 2], as, ses); fx_add(&ls[g * 2 + 1], aq, seq); });   // (the sample is L2-resident)
     __syncthreads();
     if (tid < groups) {
         const float inv = 1.0f / ((float)S * (float)cg);
-        const float ms = ls[tid * 2] * inv;
-        float var = ls[tid * 2 + 1] * inv - ms * ms;
+        const float ms = fx_get(ls[tid * 2], ses) * inv;
+        float var = fx_get(ls[tid * 2 + 1], seq) * inv - ms * ms;
         if (var < 0.f) var = 0.f;
         stat[tid * 2] = ms + gn_shift(x0, c0, x1, c1, (size_t)b * S, tid, cg);
         stat[tid * 2 + 1] = rsqrtf(var + eps);
