@@ -1,5 +1,7 @@
 """One GEMM shape under every instantiated tile (development probe): us per launch, warm, back to back.
-    python tools/probes/tile_ab.py M N K [M N K ...]"""
+    python tools/probes/tile_ab.py M N K [M N K ...]
+MODE=geglu: the LayerNorm-folded GEGLU projection (N = 2 x hidden; value * GELU(gate) epilogue, row statistics from a buffer);
+MODE=qkv: LayerNorm-folded plain projection (no residual)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "versatile-diffusion_amd"))
@@ -38,11 +40,18 @@ for i in range(0, len(args), 3):
     b = torch.randn(N, device=dev, dtype=torch.float16)
     r = torch.randn(M, N, device=dev, dtype=torch.float16)
     row = []
+    mode = os.environ.get("MODE", "")
+    cs = w.float().sum(1).contiguous()
+    fn = lambda: ops.gemm(a, w, bias=b, res=r)
+    if mode == "geglu":
+        fn = lambda: ops.linear(a, w, b, act=ops.ACT_GEGLU, colsum=cs, ln_eps=1e-5)
+    elif mode == "qkv":
+        fn = lambda: ops.linear(a, w, b, colsum=cs, ln_eps=1e-5)
     for cfg in [-1] + list(range(lib().vd_gemm_num_configs())):
         if lib().vd_gemm_set_override(cfg) != 0:
             continue
         try:
-            us = timeit(lambda: ops.gemm(a, w, bias=b, res=r))
+            us = timeit(fn)
             row.append("%s=%.1f" % ("auto" if cfg < 0 else cfg, us))
         except Exception as e:
             row.append("%d=err" % cfg)
